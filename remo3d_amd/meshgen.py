@@ -1,0 +1,309 @@
+"""Seeded synthetic mesh makers for the ReMo3D hot path (no Gmsh / Netgen in the image).
+
+The reference obtains its meshes from Gmsh (gmsh_functions.py:384-684) or Netgen
+(netgen_functions.py:120-335); both are third-party and absent here, and meshing is outside the
+hot path ("mesh generation excluded").  These makers produce the *input* of
+the hot path - straight-sided triangle / tetrahedron meshes of the reference's domain:
+
+* 2D: half disc  {(r, z): r >= 0, r^2 + z^2 <= R^2}           (gmsh_functions.py:392-449)
+* 3D: half ball  {(x, y, z): y >= 0, |x| <= R}                 (gmsh_functions.py:581, angle3 = pi)
+
+graded with the reference's background size field (gmsh_functions.py:487-500, 630-643)
+
+    h(x) = min(rho + 0.1,  min_s (d_s^2 / 2 + 0.01)),
+
+rho = distance from the borehole axis, d_s = distance from current electrode s.  (In 3D the
+reference's field string uses ``y`` where ``z`` is meant, gmsh_functions.py:637 / SURVEY.md
+section 7.3-5; the intended, 2D-consistent form is used here and stated in DESIGN.md.)
+
+Method: a graded quadtree/octree is refined until every leaf is smaller than h on it; leaf
+corners and leaf centres (a body-centred lattice, whose Delaunay triangulation is well shaped)
+are triangulated with scipy.spatial.Delaunay (the domains are convex).  Points near the outer
+sphere are projected onto it; electrode positions are snapped onto axis vertices.  Material
+numbers are assigned by element centroid through a caller-supplied function, so interfaces are
+resolved to within one (locally refined) element - the meshes are benchmark inputs, not a
+replacement for a CAD mesher.
+
+Outputs are plain arrays in exactly the layout of ``remo_mesh_t`` (include/remo3d_hip.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class Mesh:
+    dim: int
+    coords: np.ndarray      # [n_nodes, dim] float64
+    conn: np.ndarray        # [n_elems, dim+1] int32
+    mat: np.ndarray         # [n_elems] int32 (0-based index into sigma)
+    bconn: np.ndarray       # [n_bfacets, dim] int32
+    bdirichlet: np.ndarray  # [n_bfacets] uint8
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_nodes(self) -> int:
+        return int(self.coords.shape[0])
+
+    @property
+    def n_elems(self) -> int:
+        return int(self.conn.shape[0])
+
+
+def size_field(pts: np.ndarray, dim: int, sources_z: Sequence[float], scale: float = 1.0,
+               h_axis: float = 0.1, h_src: float = 0.01) -> np.ndarray:
+    """Reference background mesh size at points (gmsh_functions.py:487-500 / 630-643)."""
+    if dim == 2:
+        rho = np.abs(pts[:, 0]); z = pts[:, 1]
+    else:
+        rho = np.hypot(pts[:, 0], pts[:, 1]); z = pts[:, 2]
+    h = rho + h_axis
+    for zs in sources_z:
+        h = np.minimum(h, 0.5 * (rho * rho + (z - zs) ** 2) + h_src)
+    return scale * h
+
+
+def _refine_tree(dim: int, R: float, sources_z, scale, h_axis, h_src, max_level: int, h_max: float):
+    """Breadth-first graded quadtree / octree.  Returns leaves as (integer origin [m, dim], level[m])."""
+    # root cells have side R; axis and symmetry plane lie on cell boundaries at every level.
+    if dim == 2:
+        roots = np.array([[0, -1], [0, 0]], dtype=np.int64)
+    else:
+        roots = np.array([[ix, 0, iz] for ix in (-1, 0) for iz in (-1, 0)], dtype=np.int64)
+    src = np.asarray(list(sources_z), dtype=np.float64)
+    leaves_o, leaves_l = [], []
+    cells = roots
+    for level in range(max_level + 1):
+        if cells.shape[0] == 0:
+            break
+        s = R / (1 << level)
+        lo = cells * s
+        hi = lo + s
+        # smallest value of the size field on the closed cell (h grows with both distances), times
+        # 1.5: a body-centred cell of side s has edges s and 0.87 s and sides come in powers of two
+        if dim == 2:
+            rho_min = np.maximum(lo[:, 0], 0.0)
+            zl, zh = lo[:, 1], hi[:, 1]
+        else:
+            dx = np.maximum(np.maximum(lo[:, 0], -hi[:, 0]), 0.0)
+            dy = np.maximum(lo[:, 1], 0.0)
+            rho_min = np.hypot(dx, dy)
+            zl, zh = lo[:, 2], hi[:, 2]
+        hmin = rho_min + h_axis
+        for zs in src:
+            dz = np.maximum(np.maximum(zl - zs, zs - zh), 0.0)
+            hmin = np.minimum(hmin, 0.5 * (rho_min ** 2 + dz ** 2) + h_src)
+        hmin = 1.5 * np.minimum(scale * hmin, h_max)
+        # cells completely outside the ball are dropped
+        near = np.where(np.abs(lo) < np.abs(hi), lo, hi)
+        near = np.where((lo <= 0) & (hi >= 0), 0.0, near)
+        outside = np.sqrt((near ** 2).sum(1)) > R
+        split = (s > hmin) & (~outside) & (level < max_level)
+        keep = (~split) & (~outside)
+        leaves_o.append(cells[keep]); leaves_l.append(np.full(int(keep.sum()), level, dtype=np.int64))
+        par = cells[split]
+        if par.shape[0] == 0:
+            cells = par
+            continue
+        offs = np.array(np.meshgrid(*[[0, 1]] * dim, indexing="ij")).reshape(dim, -1).T
+        cells = (par[:, None, :] * 2 + offs[None, :, :]).reshape(-1, dim)
+    return np.concatenate(leaves_o), np.concatenate(leaves_l)
+
+
+def _lattice_points(dim, R, origins, levels, max_level):
+    """Leaf corners + centres on an integer grid of resolution R / 2^(max_level+1); deduplicated.
+    Returns (points float64, local cell size per point, is_centre)."""
+    shift = (max_level + 1) - levels                     # cell side in grid units = 2^shift
+    side = (1 << shift).astype(np.int64)
+    base = origins * side[:, None]
+    offs = np.array(np.meshgrid(*[[0, 1]] * dim, indexing="ij")).reshape(dim, -1).T
+    corners = (base[:, None, :] + offs[None, :, :] * side[:, None, None]).reshape(-1, dim)
+    csize = np.repeat(side, offs.shape[0])
+    centres = base + (side // 2)[:, None]
+    allp = np.concatenate([corners, centres])
+    alls = np.concatenate([csize, side])
+    isc = np.concatenate([np.zeros(corners.shape[0], bool), np.ones(centres.shape[0], bool)])
+    # dedupe keeping the smallest local size
+    order = np.lexsort((alls,) + tuple(allp[:, k] for k in range(dim - 1, -1, -1)))
+    allp, alls, isc = allp[order], alls[order], isc[order]
+    first = np.ones(allp.shape[0], bool)
+    first[1:] = np.any(allp[1:] != allp[:-1], axis=1)
+    unit = R / (1 << (max_level + 1))
+    return allp[first].astype(np.float64) * unit, alls[first].astype(np.float64) * unit, isc[first]
+
+
+def _boundary_facets(conn: np.ndarray):
+    """Facets that belong to exactly one element."""
+    nb = conn.shape[1]
+    faces = []
+    for k in range(nb):
+        idx = [j for j in range(nb) if j != k]
+        faces.append(conn[:, idx])
+    faces = np.sort(np.concatenate(faces), axis=1)
+    order = np.lexsort(tuple(faces[:, k] for k in range(faces.shape[1] - 1, -1, -1)))
+    fs = faces[order]
+    same_next = np.zeros(fs.shape[0], bool)
+    same_next[:-1] = np.all(fs[1:] == fs[:-1], axis=1)
+    same_prev = np.zeros(fs.shape[0], bool)
+    same_prev[1:] = same_next[:-1]
+    return fs[~(same_next | same_prev)]
+
+
+def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), scale: float = 1.0,
+              material_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None, seed: int = 0,
+              h_axis: float = 0.1, h_src: float = 0.01, max_level: int = 18,
+              snap_z: Sequence[float] = (), h_max: Optional[float] = None, jitter: float = 0.12) -> Mesh:
+    """Graded Delaunay mesh of the reference's half disc (dim=2) or half ball (dim=3).
+
+    sources_z : axis positions of current electrodes (refinement centres, snapped to vertices)
+    scale     : global multiplier on the size field (scale < 1 -> finer mesh)
+    material_fn(centroids[m, dim]) -> int array of material numbers (0-based); default all 0
+    snap_z    : further axis positions to snap onto vertices (e.g. measuring electrodes)
+    h_max     : cap on the size field (default R/5; keeps the polyhedral outer boundary round)
+    jitter    : seeded displacement of interior lattice points, fraction of the local cell size
+    """
+    from scipy.spatial import Delaunay, cKDTree
+
+    rng = np.random.default_rng(seed)
+    if h_max is None:
+        h_max = 0.2 * R
+    origins, levels = _refine_tree(dim, R, sources_z, scale, h_axis, h_src, max_level, h_max)
+    pts, hs, isc = _lattice_points(dim, R, origins, levels, max_level)
+
+    rad = np.sqrt((pts ** 2).sum(1))
+    on_axis = (pts[:, 0] == 0.0) if dim == 2 else ((pts[:, 0] == 0.0) & (pts[:, 1] == 0.0))
+    # points near / beyond the outer sphere: corners are projected onto it, centres dropped
+    band = 0.5 * hs
+    proj = (~isc) & (rad > R - band) & (rad < R + band) & (rad > 0)
+    drop = (rad >= R + band) | (isc & (rad > R - 0.6 * hs)) | ((~isc) & (~proj) & (rad > R - band))
+    pts[proj] *= (R / rad[proj])[:, None]
+    keep = ~drop
+    pts, hs, isc, proj, on_axis = pts[keep], hs[keep], isc[keep], proj[keep], on_axis[keep]
+    # exact poles / rim
+    if dim == 2:
+        extra = np.array([[0.0, -R], [0.0, R], [R, 0.0]])
+    else:
+        extra = np.array([[0.0, 0.0, -R], [0.0, 0.0, R], [R, 0.0, 0.0], [-R, 0.0, 0.0], [0.0, R, 0.0]])
+    pts = np.concatenate([pts, extra]); hs = np.concatenate([hs, np.full(len(extra), hs.max())])
+    proj = np.concatenate([proj, np.ones(len(extra), bool)])
+    on_axis = np.concatenate([on_axis, np.zeros(len(extra), bool)])
+    # merge near-duplicates created by the projection
+    tree = cKDTree(pts)
+    dd, ii = tree.query(pts, k=2)
+    dup = (dd[:, 1] < 0.3 * np.minimum(hs, hs[ii[:, 1]])) & (ii[:, 1] < np.arange(len(pts))) & proj
+    pts, hs, proj, on_axis = pts[~dup], hs[~dup], proj[~dup], on_axis[~dup]
+
+    # jitter strictly interior, off-plane points to break lattice degeneracies (seeded)
+    on_plane = np.zeros(len(pts), bool) if dim == 2 else (pts[:, 1] == 0.0)
+    if dim == 2:
+        on_plane = pts[:, 0] == 0.0
+    free = (~proj) & (~on_plane)
+    pts[free] += (rng.random((int(free.sum()), dim)) - 0.5) * (jitter * hs[free])[:, None]
+    if dim == 3:  # in-plane jitter for symmetry-plane points that are not on the axis
+        pl = on_plane & (~on_axis) & (~proj)
+        j = (rng.random((int(pl.sum()), 3)) - 0.5) * (jitter * hs[pl])[:, None]
+        j[:, 1] = 0.0
+        pts[pl] += j
+
+    # snap electrodes onto the nearest axis vertex
+    ax_idx = np.nonzero(on_axis & (~proj))[0]
+    zc = dim - 1
+    for zs in list(sources_z) + list(snap_z):
+        if abs(zs) >= R or ax_idx.size == 0:
+            continue
+        k = ax_idx[np.argmin(np.abs(pts[ax_idx, zc] - zs))]
+        pts[k, zc] = zs
+
+    # Qhull is ~10x slower on exactly coplanar hull points (symmetry plane / axis): triangulate a
+    # copy lifted off the plane by ~1e-9 R, then use the exact coordinates; the flat hull elements
+    # this creates have exactly zero measure afterwards and are removed below.
+    lifted = pts.copy()
+    lift_mask = on_plane.copy()
+    lifted[lift_mask, 0 if dim == 2 else 1] += (0.5 + rng.random(int(lift_mask.sum()))) * 1e-9 * R
+    tri = Delaunay(lifted)
+    conn = tri.simplices.astype(np.int64)
+    # drop flat elements (coplanar hull points) and elements with every vertex on the sphere
+    P = pts[conn]
+    if dim == 2:
+        a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]
+        vol = 0.5 * np.abs(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
+    else:
+        a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]; c = P[:, 3] - P[:, 0]
+        vol = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c))) / 6.0
+    emax = np.zeros(len(conn))
+    for i in range(dim + 1):
+        for j in range(i + 1, dim + 1):
+            emax = np.maximum(emax, np.sqrt(((P[:, i] - P[:, j]) ** 2).sum(1)))
+    on_sph = np.sqrt((pts ** 2).sum(1)) >= R * (1 - 1e-12)
+    ok = (vol > 1e-9 * emax ** dim) & (~np.all(on_sph[conn], axis=1))
+    conn = conn[ok]; vol = vol[ok]
+
+    # remove unused points, renumber along a Morton-like order for locality (sort by tree cell)
+    used = np.zeros(len(pts), bool); used[conn.ravel()] = True
+    q = np.floor((pts - pts.min(0)) / (pts.max(0) - pts.min(0) + 1e-300) * 1023).astype(np.int64)
+    key = np.zeros(len(pts), dtype=np.int64)
+    for bit in range(10):
+        for k in range(dim):
+            key |= ((q[:, k] >> bit) & 1) << (bit * dim + k)
+    order = np.argsort(key, kind="stable")
+    order = order[used[order]]
+    new_id = np.full(len(pts), -1, dtype=np.int64); new_id[order] = np.arange(order.size)
+    pts = pts[order]; conn = new_id[conn]
+
+    bf = _boundary_facets(conn)
+    rad = np.sqrt((pts ** 2).sum(1))
+    bdir = np.all(rad[bf] >= R * (1 - 1e-9), axis=1)
+    cent = pts[conn].mean(1)
+    mat = np.zeros(len(conn), dtype=np.int32) if material_fn is None else np.asarray(material_fn(cent), dtype=np.int32)
+    exact = (np.pi * R * R / 2) if dim == 2 else (2.0 / 3.0 * np.pi * R ** 3)
+    meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z],
+                volume=float(vol.sum()), volume_exact=float(exact))
+    return Mesh(dim, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)),
+                np.ascontiguousarray(mat), np.ascontiguousarray(bf.astype(np.int32)),
+                np.ascontiguousarray(bdir.astype(np.uint8)), meta)
+
+
+# ---------------------------------------------------------------------------------------------
+# material models (centroid classification) for the reference's benchmark inputs
+
+
+def layered_material_fn(dim: int, local_formation_geometry: np.ndarray, local_borehole_geometry: np.ndarray,
+                        dip_rad: float = 0.0):
+    """Material classifier for a windowed model as produced by geometry.select_gmsh_data_range.
+
+    Material order follows the reference (gmsh_functions.py:172, 452-480 / 591-624):
+    0 = borehole mud, then for every layer from top (smallest z in the local frame) to bottom:
+    its flushed zone (if FZ_RADIUS is not NaN) followed by its undisturbed zone.
+    local_formation_geometry: [L, 3] = (top, bottom, fz_radius) relative to the batch centre.
+    local_borehole_geometry : [B, 2] = (z, radius) relative to the batch centre.
+    The local frame has z increasing with depth, as in the reference's Gmsh models.
+    """
+    fg = np.asarray(local_formation_geometry, dtype=np.float64)
+    bg = np.asarray(local_borehole_geometry, dtype=np.float64)
+    first = []
+    k = 1
+    for i in range(fg.shape[0]):
+        first.append(k)
+        k += 1 if np.isnan(fg[i, 2]) else 2
+    first = np.asarray(first)
+    tan_d = np.tan(dip_rad)
+
+    def fn(c: np.ndarray) -> np.ndarray:
+        if dim == 2:
+            rho = np.abs(c[:, 0]); z = c[:, 1]; zl = z
+        else:
+            rho = np.hypot(c[:, 0], c[:, 1]); z = c[:, 2]
+            zl = z + tan_d * c[:, 0]     # dipping planes: slab rotated about y (gmsh_functions.py:610-611)
+        rb = np.interp(z, bg[:, 0], bg[:, 1])
+        li = np.clip(np.searchsorted(fg[:, 1], zl, side="right"), 0, fg.shape[0] - 1)
+        m = first[li].copy()
+        fz = fg[li, 2]
+        undisturbed = (~np.isnan(fz)) & (rho >= np.where(np.isnan(fz), 0.0, fz))
+        m[undisturbed] += 1
+        m[rho < rb] = 0
+        return m
+
+    return fn

@@ -1,0 +1,151 @@
+/*
+ * remo3d_hip.h — C ABI of libremo3d_hip.so: the MI355X (gfx950) replacement for ReMo3D's
+ * per-measurement-point FEM hot path.
+ *
+ * Reference interface replaced (eMWu94/ReMo3D @ 2025-04-04):
+ *   remo3d/ngsolve_functions.py:23-58      SolveBVP(mesh, sigma, tool_geometry, source_terms,
+ *                                                   dirichlet_boundary, preconditioner, condense)
+ *   remo3d/ngsolve_functions_gpu.py:15-54  the same entry, CUDA attempt (the plugin slot)
+ *   remo3d/workers/worker.py:100-134       sigma wrapping, loop over the RHS of one batch,
+ *                                          evaluation of gfu at the measuring electrodes
+ * Because `mesh` and `gfu` are NGSolve objects in the reference, the native boundary sits one
+ * step outside SolveBVP: it takes the arrays that define one batch (mesh + sigma + the point
+ * sources of every right-hand side + the axis points where the potential is read) and returns
+ * the potentials.  See INTEGRATION.md for the ctypes binding a ReMo3D maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; the library never
+ * keeps a host pointer past return.  Return codes: 0 ok, >0 warning (REMO_NOT_CONVERGED — the
+ * reference is silent about that, ngsolve_functions.py:50), <0 error (outputs NaN-filled, which
+ * reproduces the reference's NaN-per-batch convention, worker.py:135-138).  No C++ exception
+ * crosses the ABI.  One context per GPU, one calling thread per context.
+ */
+#ifndef REMO3D_HIP_H
+#define REMO3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REMO_ABI_VERSION 1
+#define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
+
+#define REMO_OK 0
+#define REMO_NOT_CONVERGED 1
+#define REMO_ERR_ARG (-1)
+#define REMO_ERR_DEVICE (-2)
+#define REMO_ERR_MESH (-3)   /* inconsistent mesh (bad index, boundary facet not in mesh, ...) */
+#define REMO_ERR_POINT (-4)  /* source / evaluation point outside the mesh */
+#define REMO_ERR_NUMERIC (-5) /* breakdown (non-finite residual) */
+
+/* One batch mesh = what worker.py:100 wraps with ngs.Mesh(): straight-sided simplices. */
+typedef struct {
+    int32_t dim;               /* 2 = axisymmetric (r, z) half disc; 3 = (x, y, z) half ball      */
+    int64_t n_nodes;
+    const double *coords;      /* [n_nodes * dim] row-major, metres, batch-centred frame          */
+    int64_t n_elems;
+    const int32_t *conn;       /* [n_elems * (dim+1)] 0-based vertex numbers, any orientation     */
+    const int32_t *mat;        /* [n_elems] 0-based index into sigma (gmsh_functions.py:332-361)  */
+    int64_t n_bfacets;
+    const int32_t *bconn;      /* [n_bfacets * dim] boundary facets                               */
+    const uint8_t *bdirichlet; /* [n_bfacets] 1 => u = 0 there (H1(..., dirichlet=...), :27)       */
+} remo_mesh_t;
+
+/* Solver options; zero-initialise then call remo_opts_default(). */
+typedef struct {
+    int32_t preconditioner; /* 0 = "local" (Jacobi, ngsolve_functions.py:46); 1 = "multigrid" => best available */
+    int32_t condense;       /* static condensation of the 2D cell bubble (ngsolve_functions.py:31) */
+    int32_t maxsteps;       /* CG step limit, reference 1000 (ngsolve_functions.py:50)             */
+    int32_t check_every;    /* host looks at the residual history every this many steps            */
+    double rtol;            /* stop when sqrt(<Cr,r>) <= rtol * sqrt(<Cr0,r0>); NGSolve default 1e-8 */
+    int32_t time_kernels;   /* 1 = bracket every SpMV launch with HIP events (bench roofline)      */
+    int32_t reserved[5];
+} remo_opts_t;
+
+typedef struct {
+    int64_t n_dof;   /* dofs before Dirichlet elimination (condensed bubbles not counted)          */
+    int64_t n_free;  /* rows of the linear system                                                 */
+    int64_t nnz;     /* stored entries of the CSR matrix                                          */
+    int64_t n_edges, n_faces;
+    int32_t n_rhs;
+    int32_t max_iterations;              /* over the RHS                                           */
+    int32_t iterations[REMO_MAX_RHS];    /* of the last chunk                                      */
+    double relres[REMO_MAX_RHS];         /* sqrt(<Cr,r>/<Cr0,r0>) of the last chunk                */
+    double ms_symbolic;  /* dof numbering + CSR pattern                                            */
+    double ms_h2d;       /* uploads                                                                */
+    double ms_assemble;  /* geometry terms + CSR values (device, HIP events)                       */
+    double ms_solve;     /* PCG, all RHS (device, HIP events)                                      */
+    double ms_eval;      /* point location + RHS build + evaluation                                */
+    double ms_total;     /* wall clock of the call                                                 */
+    double spmv_ms;      /* sum of event-timed SpMV launches (time_kernels = 1)                    */
+    int64_t spmv_launches;
+    double spmv_bytes;   /* algorithmic bytes of ONE SpMV launch: 12 nnz + 4 n + 16 k n            */
+    int64_t pcg_steps;   /* total PCG steps executed on the device (incl. post-convergence slack)  */
+} remo_stats_t;
+
+typedef struct remo_ctx remo_ctx_t;
+typedef struct remo_batch remo_batch_t;
+
+int remo_abi_version(void);
+void remo_opts_default(remo_opts_t *opts);
+
+/* One context per GPU (hipSetDevice(device_id), one stream, a grow-only device arena). */
+remo_ctx_t *remo_ctx_create(int device_id);
+void remo_ctx_destroy(remo_ctx_t *ctx);
+/* Text of the last error on this context (or of the failed remo_ctx_create when ctx == NULL). */
+const char *remo_last_error(remo_ctx_t *ctx);
+
+/*
+ * Whole batch in one call: the inner hot loop of worker.py:104-131.
+ * RHS k has point sources src_z[src_ptr[k] .. src_ptr[k+1]) on the borehole axis with strengths
+ * src_I (zero strengths are skipped, ngsolve_functions.py:43) and is read at axis positions
+ * eval_z[eval_ptr[k] .. eval_ptr[k+1]).  u_out[eval_ptr[n_rhs]] receives u_h at those points
+ * (the raw FE potential; the 1/2 of the 3D half-space model and the geometric factor are applied
+ * by the caller as in worker.py:124-131).
+ */
+int remo_solve_batch(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma,
+                     int32_t n_rhs, const int32_t *src_ptr, const double *src_z, const double *src_I,
+                     const int32_t *eval_ptr, const double *eval_z, double *u_out,
+                     const remo_opts_t *opts, remo_stats_t *stats);
+
+/*
+ * Staged form of the same work, for callers that keep a batch resident (bench.py: inputs are in
+ * HBM before the timed region).  create = validate + upload; run = numbering, pattern, assembly,
+ * PCG, evaluation, all RHS; fetch = potentials to the host.
+ */
+int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma,
+                      int32_t n_rhs, const int32_t *src_ptr, const double *src_z, const double *src_I,
+                      const int32_t *eval_ptr, const double *eval_z, remo_batch_t **out);
+int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *batch, const remo_opts_t *opts, remo_stats_t *stats);
+int remo_batch_fetch(remo_ctx_t *ctx, remo_batch_t *batch, double *u_out);
+void remo_batch_destroy(remo_ctx_t *ctx, remo_batch_t *batch);
+
+/*
+ * Inspection hooks used by the parity tests (tests/): the assembled system of the last
+ * remo_batch_run on this batch.  Pass NULL to skip an array.  rowptr[n_free+1], col[nnz],
+ * val[nnz], dinv[n_free] (Jacobi), freeid[n_dof] (free row of each dof or -1).
+ */
+int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *batch, int32_t *rowptr, int32_t *col,
+                          double *val, double *dinv, int32_t *freeid);
+/* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
+ * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */
+int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *x, double *y,
+                    int32_t reps, double *ms_avg);
+
+/*
+ * Host-side pieces exposed for CPU-only tests (no GPU needed):
+ *  - the pre-integrated reference tensors contracted with one element's metric terms, i.e. the
+ *    element matrix the assembly kernel gathers from (nld x nld, nld = 10 or 20);
+ *  - dof numbering + CSR pattern of a mesh.
+ */
+int remo_host_element_matrix(int32_t dim, const double *vertex_coords /*[(dim+1)*dim], sorted vertices*/,
+                             double sigma, double *K_out);
+int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes /*[6]: n_dof,n_free,nnz,n_edges,n_faces,nld*/,
+                       int32_t *rowptr /*[n_free+1] or NULL*/, int32_t *col /*[nnz] or NULL*/,
+                       int32_t *freeid /*[n_dof] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMO3D_HIP_H */

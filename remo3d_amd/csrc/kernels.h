@@ -1,0 +1,67 @@
+// kernels.h — launchers of the gfx950 kernels (kernels.hip).  All launches are asynchronous on
+// the given stream; no launcher allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace remo {
+
+constexpr int kMaxPartialBlocks = 1024;  // grid cap of every kernel that leaves per-block partial sums
+constexpr int kMaxPoints = 256;          // sources + evaluation points of one RHS chunk
+
+// per-iteration record the PCG kernels write straight into mapped host memory
+struct PcgProgress {
+    double rz[8];        // <Cr,r> per column at the START of step `step`
+    int32_t step;        // written last
+    int32_t pad;
+};
+
+struct PcgBuffers {
+    double *x, *r, *p, *q;  // [n*k]
+    const double *dinv;     // [n]
+    double *part_pq;        // [kMaxPartialBlocks*8]
+    double *part_rz;        // [2][kMaxPartialBlocks*8]
+    double *rz0;            // [8] device copy of <Cr0,r0>
+    PcgProgress *progress;  // mapped host ring [progress_len]
+    int progress_len;
+    int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
+};
+
+struct CsrView {
+    int64_t n;
+    int64_t nnz;
+    const int32_t *rowptr;
+    const int32_t *col;
+    const double *val;
+};
+
+void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,
+                         const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s);
+void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowptr, const int32_t *col,
+                     const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
+                     const double *M, double *val, double *dinv, hipStream_t s);
+
+int spmv_grid(int64_t n, int lanes_per_row);
+int choose_lanes_per_row(int64_t n, int64_t nnz);
+// y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of x.y
+void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nblocks, hipStream_t s);
+
+void launch_pcg_init(int64_t n, int k, const double *f, const PcgBuffers &b, hipStream_t s);
+void launch_pcg_update(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
+void launch_pcg_direction(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
+void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s);
+
+// point location on the borehole axis + shape values; found[] must be pre-set to INT_MAX
+void launch_locate(int dim, int64_t nt, const double *coords, const int32_t *conn, int npts, const double *pz,
+                   int32_t *found, hipStream_t s);
+void launch_point_shapes(int dim, int npts, const double *pz, const int32_t *found, const double *coords,
+                         const int32_t *conn, double *phi, int32_t *errflag, hipStream_t s);
+// f[n*k] += I * phi at sources (with the condensed-bubble fold in 2D); bubble loads kept in fint[npts]
+void launch_build_rhs(int dim, bool condense, int npts, const int32_t *pt_rhs, const double *pt_I,
+                      const int32_t *found, const double *phi, const int32_t *eldof, const double *C,
+                      const double *M, int k, double *f, double *fint, hipStream_t s);
+void launch_eval(int dim, bool condense, int npts, const int32_t *pt_rhs, const double *pt_I, const int32_t *found,
+                 const double *phi, const int32_t *eldof, const double *C, const double *M, int k,
+                 const double *x, const double *fint, double *out, hipStream_t s);
+
+}  // namespace remo

@@ -1,0 +1,663 @@
+// remo_api.hip — the C ABI of include/remo3d_hip.h: context, resident batches, and the host
+// orchestration of one batch (numbering -> upload -> assembly -> multi-RHS PCG -> evaluation).
+// The orchestration mirrors the inner loop of remo3d/workers/worker.py:100-134 with one
+// difference the reference leaves on the table: the matrix of a batch is
+// assembled once and all its right-hand sides are solved together.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/remo3d_hip.h"
+#include "fem_p3.h"
+#include "kernels.h"
+#include "symbolic.h"
+
+using namespace remo;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            char buf__[512];                                                                            \
+            snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            throw std::runtime_error(buf__);                                                            \
+        }                                                                                               \
+    } while (0)
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct remo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    double *d_M2 = nullptr, *d_M3 = nullptr;
+    PcgProgress *progress = nullptr;  // mapped, coherent host memory
+    PcgProgress *progress_dev = nullptr;
+    int progress_len = 0;
+    int32_t *d_err = nullptr;
+    hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> spmv_ev;
+
+    template <class T> T *take(size_t count) {
+        const size_t bytes = align_up(count * sizeof(T));
+        if (arena_off + bytes > arena_cap) throw std::runtime_error("device arena exhausted (internal sizing error)");
+        T *p = reinterpret_cast<T *>(arena + arena_off);
+        arena_off += bytes;
+        return p;
+    }
+    void reserve(size_t bytes) {
+        arena_off = 0;
+        if (bytes <= arena_cap) return;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (arena) HIP_TRY(hipFree(arena));
+        arena = nullptr;
+        arena_cap = 0;
+        const size_t want = bytes + bytes / 4;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&arena), want));
+        arena_cap = want;
+    }
+    void ensure_progress(int len) {
+        if (len <= progress_len) return;
+        if (progress) HIP_TRY(hipHostFree(progress));
+        progress = nullptr;
+        progress_len = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&progress), sizeof(PcgProgress) * size_t(len),
+                              hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&progress_dev), progress, 0));
+        progress_len = len;
+    }
+};
+
+struct remo_batch {
+    // host copy of the mesh (the numbering pass runs on the host cores)
+    int dim = 0;
+    std::vector<double> coords;
+    std::vector<int32_t> conn, mat, bconn;
+    std::vector<uint8_t> bdir;
+    std::vector<double> sigma;
+    // points: per chunk [sources..., evals...]
+    int n_rhs = 0;
+    std::vector<int32_t> src_ptr, eval_ptr;
+    std::vector<double> src_z, src_I, eval_z;
+    // resident device inputs
+    double *d_coords = nullptr, *d_sigma = nullptr;
+    int32_t *d_mat = nullptr;
+    // last system (pointers into the context arena; valid until the next run on the context)
+    bool has_system = false;
+    Symbolic sym;
+    CsrView A{};
+    double *d_val = nullptr, *d_dinv = nullptr;
+    std::vector<double> u_out;
+};
+
+namespace {
+
+remo_mesh_t mesh_view(const remo_batch &b) {
+    remo_mesh_t m;
+    m.dim = b.dim;
+    m.n_nodes = int64_t(b.coords.size()) / b.dim;
+    m.coords = b.coords.data();
+    m.n_elems = int64_t(b.mat.size());
+    m.conn = b.conn.data();
+    m.mat = b.mat.data();
+    m.n_bfacets = int64_t(b.bdir.size());
+    m.bconn = b.bconn.data();
+    m.bdirichlet = b.bdir.data();
+    return m;
+}
+
+int fail(remo_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// spin on the mapped progress record until the device has reached `step`; falls back to a
+// stream synchronisation (which also publishes the record) after `timeout_ms`.
+bool wait_progress(remo_ctx *ctx, int step, double timeout_ms) {
+    volatile int32_t *flag = &ctx->progress[step % ctx->progress_len].step;
+    const double t0 = now_ms();
+    int spins = 0;
+    while (*flag != step) {
+        if (++spins > 64) {
+            std::this_thread::yield();
+            if (now_ms() - t0 > timeout_ms) {
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                return *flag == step;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+
+struct ChunkResult {
+    int steps = 0;
+    bool converged = false;
+    bool finite = true;
+    int iters[REMO_MAX_RHS];
+    double relres[REMO_MAX_RHS];
+};
+
+ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, PcgBuffers &buf, const remo_opts_t &o,
+                    remo_stats_t *st, size_t &ev_used) {
+    ChunkResult res;
+    hipStream_t s = ctx->stream;
+    const double tol2 = o.rtol * o.rtol;
+    const int maxit = o.maxsteps;
+    const int check = o.check_every > 0 ? o.check_every : 10;
+    for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    launch_pcg_init(A.n, k, d_f, buf, s);
+    int step = 0;
+    bool done = false;
+    for (; step < maxit && !done;) {
+        if (o.time_kernels && ev_used + 2 <= ctx->spmv_ev.size()) {
+            HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
+            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.nb_spmv, s);
+            HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
+            ev_used += 2;
+        } else {
+            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.nb_spmv, s);
+        }
+        launch_pcg_update(A.n, k, step, tol2, buf, s);
+        launch_pcg_direction(A.n, k, step, tol2, buf, s);
+        ++step;
+        if (step % check == 0) {
+            const int target = step - 2 * check;  // stay two checks ahead of the device
+            if (target >= 0) {
+                if (!wait_progress(ctx, target, 2000.0)) throw std::runtime_error("PCG progress record not visible to the host");
+                const PcgProgress &pr = ctx->progress[target % ctx->progress_len];
+                const PcgProgress &p0 = ctx->progress[0];
+                bool all = true;
+                for (int c = 0; c < k; ++c) {
+                    const double r = pr.rz[c];
+                    if (!std::isfinite(r)) { res.finite = false; all = true; break; }
+                    if (r > tol2 * p0.rz[c]) all = false;
+                }
+                if (all) done = true;
+            }
+        }
+    }
+    launch_pcg_final(k, step, buf, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    res.steps = step;
+    const PcgProgress &p0 = ctx->progress[0];
+    res.converged = true;
+    for (int c = 0; c < k; ++c) {
+        res.iters[c] = step;
+        const double r0 = p0.rz[c];
+        for (int i = 0; i <= step; ++i) {
+            const PcgProgress &pr = ctx->progress[i % ctx->progress_len];
+            if (pr.step != i) continue;
+            if (!std::isfinite(pr.rz[c])) res.finite = false;
+            if (!(pr.rz[c] > tol2 * r0)) { res.iters[c] = i; break; }
+        }
+        const double rl = ctx->progress[step % ctx->progress_len].rz[c];
+        res.relres[c] = (r0 > 0.0) ? std::sqrt(rl / r0) : 0.0;
+        if (rl > tol2 * r0) res.converged = false;
+        if (!std::isfinite(rl)) res.finite = false;
+    }
+    if (st) st->pcg_steps += step;
+    return res;
+}
+
+}  // namespace
+
+extern "C" {
+
+int remo_abi_version(void) { return REMO_ABI_VERSION; }
+
+void remo_opts_default(remo_opts_t *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->preconditioner = 1;  // remo3d.py:82 default "multigrid" => best available
+    o->condense = 1;        // remo3d.py:83
+    o->maxsteps = 1000;     // ngsolve_functions.py:50
+    o->check_every = 10;
+    o->rtol = 1e-8;         // NGSolve CGSolver default precision
+    o->time_kernels = 0;
+}
+
+remo_ctx_t *remo_ctx_create(int device_id) {
+    remo_ctx *ctx = nullptr;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) {
+            g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+            return nullptr;
+        }
+        if (device_id < 0 || device_id >= ndev) {
+            g_create_error = "device_id out of range";
+            return nullptr;
+        }
+        ctx = new remo_ctx();
+        ctx->device = device_id;
+        HIP_TRY(hipSetDevice(device_id));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &ev : ctx->ev) HIP_TRY(hipEventCreate(&ev));
+        const double *m2 = ref_tables(2), *m3 = ref_tables(3);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_M2), sizeof(double) * 9 * 100));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_M3), sizeof(double) * 6 * 400));
+        HIP_TRY(hipMemcpy(ctx->d_M2, m2, sizeof(double) * 9 * 100, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_M3, m3, sizeof(double) * 6 * 400, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_err), sizeof(int32_t)));
+        ctx->ensure_progress(1024 + 2);
+        return ctx;
+    } catch (const std::exception &ex) {
+        g_create_error = ex.what();
+        delete ctx;
+        return nullptr;
+    }
+}
+
+void remo_ctx_destroy(remo_ctx_t *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->spmv_ev) hipEventDestroy(ev);
+    for (auto &ev : ctx->ev)
+        if (ev) hipEventDestroy(ev);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->d_M2) hipFree(ctx->d_M2);
+    if (ctx->d_M3) hipFree(ctx->d_M3);
+    if (ctx->d_err) hipFree(ctx->d_err);
+    if (ctx->progress) hipHostFree(ctx->progress);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *remo_last_error(remo_ctx_t *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma, int32_t n_rhs,
+                      const int32_t *src_ptr, const double *src_z, const double *src_I, const int32_t *eval_ptr,
+                      const double *eval_z, remo_batch_t **out) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!mesh || !sigma || !out || n_mat <= 0 || n_rhs <= 0 || !src_ptr || !eval_ptr)
+        return fail(ctx, REMO_ERR_ARG, "null or empty argument");
+    if (mesh->dim != 2 && mesh->dim != 3) return fail(ctx, REMO_ERR_ARG, "dim must be 2 or 3");
+    if (mesh->n_nodes <= 0 || mesh->n_elems <= 0 || !mesh->coords || !mesh->conn || !mesh->mat)
+        return fail(ctx, REMO_ERR_ARG, "empty mesh");
+    if (src_ptr[0] != 0 || eval_ptr[0] != 0) return fail(ctx, REMO_ERR_ARG, "src_ptr / eval_ptr must start at 0");
+    for (int k = 0; k < n_rhs; ++k)
+        if (src_ptr[k + 1] < src_ptr[k] || eval_ptr[k + 1] < eval_ptr[k]) return fail(ctx, REMO_ERR_ARG, "src_ptr / eval_ptr not monotone");
+    if ((src_ptr[n_rhs] > 0 && (!src_z || !src_I)) || (eval_ptr[n_rhs] > 0 && !eval_z)) return fail(ctx, REMO_ERR_ARG, "point arrays missing");
+    remo_batch *b = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        b = new remo_batch();
+        const int dim = mesh->dim, nb = dim + 1;
+        b->dim = dim;
+        b->coords.assign(mesh->coords, mesh->coords + mesh->n_nodes * dim);
+        b->conn.assign(mesh->conn, mesh->conn + mesh->n_elems * nb);
+        b->mat.assign(mesh->mat, mesh->mat + mesh->n_elems);
+        if (mesh->n_bfacets > 0) {
+            if (!mesh->bconn || !mesh->bdirichlet) { delete b; return fail(ctx, REMO_ERR_ARG, "boundary arrays missing"); }
+            b->bconn.assign(mesh->bconn, mesh->bconn + mesh->n_bfacets * dim);
+            b->bdir.assign(mesh->bdirichlet, mesh->bdirichlet + mesh->n_bfacets);
+        }
+        b->sigma.assign(sigma, sigma + n_mat);
+        b->n_rhs = n_rhs;
+        b->src_ptr.assign(src_ptr, src_ptr + n_rhs + 1);
+        b->eval_ptr.assign(eval_ptr, eval_ptr + n_rhs + 1);
+        b->src_z.assign(src_z, src_z + src_ptr[n_rhs]);
+        b->src_I.assign(src_I, src_I + src_ptr[n_rhs]);
+        b->eval_z.assign(eval_z, eval_z + eval_ptr[n_rhs]);
+        for (double c : b->coords)
+            if (!std::isfinite(c)) { delete b; return fail(ctx, REMO_ERR_MESH, "non-finite coordinate"); }
+        for (double sg : b->sigma)
+            if (!(sg > 0.0) || !std::isfinite(sg)) { delete b; return fail(ctx, REMO_ERR_ARG, "sigma must be positive and finite"); }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_coords), sizeof(double) * b->coords.size()));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mat), sizeof(int32_t) * b->mat.size()));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sigma), sizeof(double) * b->sigma.size()));
+        HIP_TRY(hipMemcpyAsync(b->d_coords, b->coords.data(), sizeof(double) * b->coords.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_mat, b->mat.data(), sizeof(int32_t) * b->mat.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_sigma, b->sigma.data(), sizeof(double) * b->sigma.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        b->u_out.assign(size_t(eval_ptr[n_rhs]), std::nan(""));
+        *out = b;
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (b) {
+            if (b->d_coords) hipFree(b->d_coords);
+            if (b->d_mat) hipFree(b->d_mat);
+            if (b->d_sigma) hipFree(b->d_sigma);
+            delete b;
+        }
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+void remo_batch_destroy(remo_ctx_t *ctx, remo_batch_t *b) {
+    if (!b) return;
+    if (ctx) hipSetDevice(ctx->device);
+    if (b->d_coords) hipFree(b->d_coords);
+    if (b->d_mat) hipFree(b->d_mat);
+    if (b->d_sigma) hipFree(b->d_sigma);
+    delete b;
+}
+
+int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in, remo_stats_t *st) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b) return fail(ctx, REMO_ERR_ARG, "null batch");
+    remo_opts_t o;
+    if (opts_in) o = *opts_in; else remo_opts_default(&o);
+    if (o.maxsteps <= 0 || !(o.rtol > 0.0)) return fail(ctx, REMO_ERR_ARG, "maxsteps and rtol must be positive");
+    remo_stats_t local;
+    if (!st) st = &local;
+    std::memset(st, 0, sizeof *st);
+    std::fill(b->u_out.begin(), b->u_out.end(), std::nan(""));
+    b->has_system = false;
+    const double t_start = now_ms();
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        // ---- numbering + pattern (host) -------------------------------------------------
+        std::string err;
+        const remo_mesh_t mv = mesh_view(*b);
+        int rc = build_symbolic(mv, o.condense != 0, true, b->sym, err);
+        if (rc != REMO_OK) return fail(ctx, rc, err);
+        const Symbolic &sy = b->sym;
+        st->ms_symbolic = now_ms() - t_start;
+        st->n_dof = sy.ndof; st->n_free = sy.nfree; st->nnz = sy.nnz; st->n_edges = sy.ne; st->n_faces = sy.nf;
+        st->n_rhs = b->n_rhs;
+        const int dim = sy.dim, nb = dim + 1, N = sy.nld_full;
+        const int NT = (dim == 2) ? 9 : 6;
+        const int64_t n = sy.nfree, nt = sy.nt;
+        const int kmax = std::min<int>(b->n_rhs, REMO_MAX_RHS);
+
+        // ---- points of all RHS, chunk by chunk: [sources..., evals...] -------------------
+        std::vector<double> pz, pI;
+        std::vector<int32_t> prhs, chunk_pt_begin, eval_slot;  // eval_slot: u_out index or -1
+        for (int c0 = 0; c0 < b->n_rhs; c0 += REMO_MAX_RHS) {
+            chunk_pt_begin.push_back(int32_t(pz.size()));
+            const int c1 = std::min(b->n_rhs, c0 + REMO_MAX_RHS);
+            for (int r = c0; r < c1; ++r)
+                for (int q = b->src_ptr[r]; q < b->src_ptr[r + 1]; ++q) {
+                    pz.push_back(b->src_z[q]); pI.push_back(b->src_I[q]); prhs.push_back(r - c0); eval_slot.push_back(-1);
+                }
+            for (int r = c0; r < c1; ++r)
+                for (int q = b->eval_ptr[r]; q < b->eval_ptr[r + 1]; ++q) {
+                    pz.push_back(b->eval_z[q]); pI.push_back(0.0); prhs.push_back(r - c0); eval_slot.push_back(q);
+                }
+        }
+        chunk_pt_begin.push_back(int32_t(pz.size()));
+        const int npts = int(pz.size());
+        for (double z : pz)
+            if (!std::isfinite(z)) return fail(ctx, REMO_ERR_POINT, "non-finite point coordinate");
+
+        // ---- device arena -----------------------------------------------------------------
+        size_t need = 0;
+        auto add = [&](size_t bytes) { need += align_up(bytes); };
+        add(sizeof(int32_t) * nt * nb); add(sizeof(int32_t) * nt * N); add(sizeof(int32_t) * (n + 1) * 2);
+        add(sizeof(int32_t) * sy.nnz); add(sizeof(uint32_t) * sy.adj.size()); add(sizeof(double) * nt * NT);
+        add(sizeof(double) * sy.nnz); add(sizeof(double) * n);
+        for (int i = 0; i < 5; ++i) add(sizeof(double) * n * kmax);  // f x r p q
+        add(sizeof(double) * kMaxPartialBlocks * 8 * 3); add(sizeof(double) * 8);
+        add(sizeof(double) * npts * 2); add(sizeof(int32_t) * npts * 2); add(sizeof(double) * npts * (N + 2));
+        ctx->reserve(need + 4096);
+        int32_t *d_conn = ctx->take<int32_t>(nt * nb);
+        int32_t *d_eldof = ctx->take<int32_t>(nt * N);
+        int32_t *d_rowptr = ctx->take<int32_t>(n + 1);
+        int32_t *d_adjptr = ctx->take<int32_t>(n + 1);
+        int32_t *d_col = ctx->take<int32_t>(sy.nnz);
+        uint32_t *d_adj = ctx->take<uint32_t>(sy.adj.size());
+        double *d_C = ctx->take<double>(nt * NT);
+        double *d_val = ctx->take<double>(sy.nnz);
+        double *d_dinv = ctx->take<double>(n);
+        double *d_f = ctx->take<double>(n * kmax);
+        PcgBuffers buf{};
+        buf.x = ctx->take<double>(n * kmax); buf.r = ctx->take<double>(n * kmax);
+        buf.p = ctx->take<double>(n * kmax); buf.q = ctx->take<double>(n * kmax);
+        buf.dinv = d_dinv;
+        buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
+        buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
+        buf.rz0 = ctx->take<double>(8);
+        double *d_pz = ctx->take<double>(npts), *d_pI = ctx->take<double>(npts);
+        int32_t *d_prhs = ctx->take<int32_t>(npts), *d_found = ctx->take<int32_t>(npts);
+        double *d_phi = ctx->take<double>(size_t(npts) * N), *d_fint = ctx->take<double>(npts), *d_out = ctx->take<double>(npts);
+        ctx->ensure_progress(o.maxsteps + 2);
+        buf.progress = ctx->progress_dev;
+        buf.progress_len = ctx->progress_len;
+        if (o.time_kernels && ctx->spmv_ev.size() < 8192) {
+            const size_t old = ctx->spmv_ev.size();
+            ctx->spmv_ev.resize(8192);
+            for (size_t i = old; i < ctx->spmv_ev.size(); ++i) HIP_TRY(hipEventCreate(&ctx->spmv_ev[i]));
+        }
+
+        // ---- uploads ----------------------------------------------------------------------
+        HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        HIP_TRY(hipMemsetAsync(ctx->d_err, 0, sizeof(int32_t), s));
+        HIP_TRY(hipMemcpyAsync(d_conn, sy.conn.data(), sizeof(int32_t) * nt * nb, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_eldof, sy.eldof.data(), sizeof(int32_t) * nt * N, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_rowptr, sy.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_adjptr, sy.adjptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_col, sy.col.data(), sizeof(int32_t) * sy.nnz, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_adj, sy.adj.data(), sizeof(uint32_t) * sy.adj.size(), hipMemcpyHostToDevice, s));
+        if (npts > 0) {
+            HIP_TRY(hipMemcpyAsync(d_pz, pz.data(), sizeof(double) * npts, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_pI, pI.data(), sizeof(double) * npts, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_prhs, prhs.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev[1], s));
+
+        // ---- assembly ---------------------------------------------------------------------
+        const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
+        launch_metric_terms(dim, nt, b->d_coords, d_conn, b->d_mat, b->d_sigma, int(b->sigma.size()), d_C, ctx->d_err, s);
+        launch_assemble(dim, sy.condense, n, d_rowptr, d_col, d_adjptr, d_adj, d_eldof, d_C, d_M, d_val, d_dinv, s);
+        HIP_TRY(hipEventRecord(ctx->ev[2], s));
+
+        // ---- point location + shapes (all points at once) ---------------------------------
+        if (npts > 0) {
+            std::vector<int32_t> init(npts, INT_MAX);
+            HIP_TRY(hipMemcpyAsync(d_found, init.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // init is a stack-lifetime buffer
+            for (int q0 = 0; q0 < npts; q0 += kMaxPoints)
+                launch_locate(dim, nt, b->d_coords, d_conn, std::min(kMaxPoints, npts - q0), d_pz + q0, d_found + q0, s);
+            launch_point_shapes(dim, npts, d_pz, d_found, b->d_coords, d_conn, d_phi, ctx->d_err, s);
+        }
+        HIP_TRY(hipEventRecord(ctx->ev[3], s));
+        int32_t h_err = 0;
+        HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
+        if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
+
+        b->A = CsrView{n, sy.nnz, d_rowptr, d_col, d_val};
+        b->d_val = d_val;
+        b->d_dinv = d_dinv;
+        b->has_system = true;
+
+        // ---- solve, chunk by chunk --------------------------------------------------------
+        const int lpr = choose_lanes_per_row(n, sy.nnz);
+        buf.nb_spmv = spmv_grid(n, lpr);
+        {
+            int64_t g = (n + 255) / 256;
+            if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
+            buf.nb_vec = int(g < 1 ? 1 : g);
+        }
+        std::vector<double> h_out(npts, std::nan(""));
+        int ret = REMO_OK;
+        size_t ev_used = 0;
+        float ms_solve = 0.f, ms_eval = 0.f;
+        int chunk = 0;
+        for (int c0 = 0; c0 < b->n_rhs; c0 += REMO_MAX_RHS, ++chunk) {
+            const int k = std::min(b->n_rhs - c0, REMO_MAX_RHS);
+            const int q0 = chunk_pt_begin[chunk], nq = chunk_pt_begin[chunk + 1] - q0;
+            HIP_TRY(hipEventRecord(ctx->ev[4], s));
+            HIP_TRY(hipMemsetAsync(d_f, 0, sizeof(double) * n * k, s));
+            if (nq > 0)
+                launch_build_rhs(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, d_eldof, d_C, d_M, k,
+                                 d_f, d_fint + q0, s);
+            HIP_TRY(hipEventRecord(ctx->ev[5], s));
+            ChunkResult cr = run_pcg(ctx, b->A, k, d_f, buf, o, st, ev_used);
+            HIP_TRY(hipEventRecord(ctx->ev[6], s));
+            if (nq > 0)
+                launch_eval(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, d_eldof, d_C, d_M, k, buf.x,
+                            d_fint + q0, d_out + q0, s);
+            HIP_TRY(hipEventRecord(ctx->ev[7], s));
+            if (nq > 0) HIP_TRY(hipMemcpyAsync(h_out.data() + q0, d_out + q0, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            float e1 = 0, e2 = 0, e3 = 0;
+            hipEventElapsedTime(&e1, ctx->ev[4], ctx->ev[5]);
+            hipEventElapsedTime(&e2, ctx->ev[5], ctx->ev[6]);
+            hipEventElapsedTime(&e3, ctx->ev[6], ctx->ev[7]);
+            ms_eval += e1 + e3;
+            ms_solve += e2;
+            if (!cr.finite) return fail(ctx, REMO_ERR_NUMERIC, "non-finite residual in PCG");
+            if (!cr.converged) ret = REMO_NOT_CONVERGED;
+            for (int c = 0; c < k; ++c) {
+                st->iterations[c] = cr.iters[c];
+                st->relres[c] = cr.relres[c];
+                st->max_iterations = std::max(st->max_iterations, cr.iters[c]);
+            }
+        }
+        for (int q = 0; q < npts; ++q)
+            if (eval_slot[q] >= 0) b->u_out[eval_slot[q]] = h_out[q];
+        float m = 0;
+        hipEventElapsedTime(&m, ctx->ev[0], ctx->ev[1]); st->ms_h2d = m;
+        hipEventElapsedTime(&m, ctx->ev[1], ctx->ev[2]); st->ms_assemble = m;
+        hipEventElapsedTime(&m, ctx->ev[2], ctx->ev[3]); st->ms_eval = m + ms_eval;
+        st->ms_solve = ms_solve;
+        st->spmv_bytes = 12.0 * double(sy.nnz) + 4.0 * double(n) + 16.0 * double(kmax) * double(n);
+        if (o.time_kernels) {
+            double sum = 0;
+            for (size_t i = 0; i + 1 < ev_used; i += 2) {
+                float e = 0;
+                hipEventElapsedTime(&e, ctx->spmv_ev[i], ctx->spmv_ev[i + 1]);
+                sum += e;
+            }
+            st->spmv_ms = sum;
+            st->spmv_launches = int64_t(ev_used / 2);
+        }
+        st->ms_total = now_ms() - t_start;
+        if (ret == REMO_NOT_CONVERGED) ctx->err = "PCG did not reach rtol within maxsteps";
+        return ret;
+    } catch (const std::exception &ex) {
+        std::fill(b->u_out.begin(), b->u_out.end(), std::nan(""));
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_batch_fetch(remo_ctx_t *ctx, remo_batch_t *b, double *u_out) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || (!u_out && !b->u_out.empty())) return fail(ctx, REMO_ERR_ARG, "null argument");
+    if (!b->u_out.empty()) std::memcpy(u_out, b->u_out.data(), sizeof(double) * b->u_out.size());
+    return REMO_OK;
+}
+
+int remo_solve_batch(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma, int32_t n_rhs,
+                     const int32_t *src_ptr, const double *src_z, const double *src_I, const int32_t *eval_ptr,
+                     const double *eval_z, double *u_out, const remo_opts_t *opts, remo_stats_t *stats) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (u_out && eval_ptr && n_rhs > 0)
+        for (int i = 0; i < eval_ptr[n_rhs]; ++i) u_out[i] = std::nan("");
+    remo_batch_t *b = nullptr;
+    int rc = remo_batch_create(ctx, mesh, n_mat, sigma, n_rhs, src_ptr, src_z, src_I, eval_ptr, eval_z, &b);
+    if (rc != REMO_OK) return rc;
+    rc = remo_batch_run(ctx, b, opts, stats);
+    if (rc >= 0 && u_out) remo_batch_fetch(ctx, b, u_out);
+    remo_batch_destroy(ctx, b);
+    return rc;
+}
+
+int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int32_t *col, double *val, double *dinv,
+                          int32_t *freeid) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || !b->has_system) return fail(ctx, REMO_ERR_ARG, "no assembled system on this batch (run it first)");
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const Symbolic &sy = b->sym;
+        if (rowptr) std::memcpy(rowptr, sy.rowptr.data(), sizeof(int32_t) * (sy.nfree + 1));
+        if (col) std::memcpy(col, sy.col.data(), sizeof(int32_t) * sy.nnz);
+        if (freeid) std::memcpy(freeid, sy.freeid.data(), sizeof(int32_t) * sy.ndof);
+        if (val) HIP_TRY(hipMemcpy(val, b->d_val, sizeof(double) * sy.nnz, hipMemcpyDeviceToHost));
+        if (dinv) HIP_TRY(hipMemcpy(dinv, b->d_dinv, sizeof(double) * sy.nfree, hipMemcpyDeviceToHost));
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x, double *y, int32_t reps, double *ms_avg) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || !b->has_system || !x || !y || k < 1 || k > REMO_MAX_RHS || reps < 1) return fail(ctx, REMO_ERR_ARG, "bad argument");
+    double *dx = nullptr, *dy = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int64_t n = b->A.n;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * n * k));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dy), sizeof(double) * n * k));
+        HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n * k, hipMemcpyHostToDevice));
+        const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
+        launch_spmm(b->A, k, dx, dy, nullptr, nb, ctx->stream);  // warm-up
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        for (int r = 0; r < reps; ++r) launch_spmm(b->A, k, dx, dy, nullptr, nb, ctx->stream);
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        if (ms_avg) *ms_avg = double(ms) / reps;
+        HIP_TRY(hipMemcpy(y, dy, sizeof(double) * n * k, hipMemcpyDeviceToHost));
+        hipFree(dx); hipFree(dy);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (dx) hipFree(dx);
+        if (dy) hipFree(dy);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_host_element_matrix(int32_t dim, const double *X, double sigma, double *K_out) {
+    if ((dim != 2 && dim != 3) || !X || !K_out) return REMO_ERR_ARG;
+    const double *M = ref_tables(dim);
+    if (dim == 2) {
+        double C[9];
+        if (!metric_terms<2>(X, sigma, C)) return REMO_ERR_MESH;
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j) K_out[i * 10 + j] = kentry<2>(C, M, i, j);
+    } else {
+        double C[6];
+        if (!metric_terms<3>(X, sigma, C)) return REMO_ERR_MESH;
+        for (int i = 0; i < 20; ++i)
+            for (int j = 0; j < 20; ++j) K_out[i * 20 + j] = kentry<3>(C, M, i, j);
+    }
+    return REMO_OK;
+}
+
+int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes, int32_t *rowptr, int32_t *col, int32_t *freeid) {
+    if (!mesh || !sizes) return REMO_ERR_ARG;
+    Symbolic sy;
+    std::string err;
+    const int rc = build_symbolic(*mesh, condense != 0, true, sy, err);
+    if (rc != REMO_OK) { g_create_error = err; return rc; }
+    sizes[0] = sy.ndof; sizes[1] = sy.nfree; sizes[2] = sy.nnz; sizes[3] = sy.ne; sizes[4] = sy.nf; sizes[5] = sy.nld;
+    if (rowptr) std::memcpy(rowptr, sy.rowptr.data(), sizeof(int32_t) * (sy.nfree + 1));
+    if (col) std::memcpy(col, sy.col.data(), sizeof(int32_t) * sy.nnz);
+    if (freeid) std::memcpy(freeid, sy.freeid.data(), sizeof(int32_t) * sy.ndof);
+    return REMO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64 everywhere): assembled CSR values 1e-12 relative to the largest entry (the two
+sides integrate differently: exact reference tensors vs per-element quadrature); SpMV 1e-13
+relative; potentials at axis points 1e-8 relative (both PCGs converged to rtol 1e-12, so the
+difference is solver error, far below the north star's 1e-6 on apparent resistivity).
+"""
+import numpy as np
+import pytest
+
+from conftest import SIGMA3
+
+pytestmark = pytest.mark.gpu
+
+SRC = [([0.0], [1.0]), ([0.1], [1.0]), ([-0.1, 0.1], [1.0, -1.0])]
+EVAL = [[0.4, 6.4, -2.0], [2.1, 2.6], [0.5, 3.0, 0.0]]
+
+
+def _oracle_solve(mesh, sigma, condense):
+    from oracle.fem_oracle import Oracle
+    o = Oracle(mesh, sigma, condense=condense)
+    outs = []
+    for (z, I), ez in zip(SRC, EVAL):
+        f, se, sf = o.rhs(z, I)
+        u, it, rr, rc = o.pcg(f, 1e-12, 50000)
+        assert rc == 0
+        outs.append(o.eval(u, ez, (se, sf)))
+    return o, outs
+
+
+@pytest.mark.parametrize("which,condense", [("2d", True), ("2d", False), ("3d", True)])
+def test_assembly_and_solve_match_oracle(which, condense, mesh2d, mesh3d, gpu_ctx):
+    from remo3d_amd import solver
+    mesh = mesh2d if which == "2d" else mesh3d
+    o, ref = _oracle_solve(mesh, SIGMA3, condense)
+    b = gpu_ctx.batch(mesh, SIGMA3, SRC, EVAL)
+    rc = b.run(solver.make_opts(preconditioner="local", condense=condense, rtol=1e-12, maxsteps=20000))
+    assert rc == 0, gpu_ctx.last_error()
+    st = b.stats
+    assert st["n_free"] == o.nfree and st["nnz"] == o.nnz
+    rowptr, col, val, dinv, freeid = b.system()
+    rp, oc, ov = o.csr()
+    assert np.array_equal(rowptr, rp) and np.array_equal(col, oc)
+    assert np.array_equal(freeid, o.freeid())
+    assert np.max(np.abs(val - ov)) <= 1e-12 * np.max(np.abs(ov))
+    diag = ov[[np.searchsorted(oc[rp[i]:rp[i + 1]], i) + rp[i] for i in range(0, o.nfree, 97)]]
+    assert np.allclose(dinv[::97] * diag, 1.0, rtol=1e-12)
+    got = b.fetch()
+    for g, r in zip(got, ref):
+        assert np.all(np.isfinite(g))
+        assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r)), (g, r)
+    # iteration counts of the two Jacobi-PCGs agree closely (same algorithm, different summation order)
+    assert max(st["iterations"][:3]) > 10
+    b.close()
+
+
+@pytest.mark.parametrize("which", ["2d", "3d"])
+@pytest.mark.parametrize("k", [1, 3, 5, 8])
+def test_spmv_matches_oracle(which, k, mesh2d, mesh3d, gpu_ctx):
+    from remo3d_amd import solver
+    mesh = mesh2d if which == "2d" else mesh3d
+    from oracle.fem_oracle import Oracle
+    o = Oracle(mesh, SIGMA3, condense=True)
+    b = gpu_ctx.batch(mesh, SIGMA3, SRC[:1], EVAL[:1])
+    b.run(solver.make_opts(preconditioner="local", rtol=1e-2))
+    rng = np.random.default_rng(k)
+    x = rng.standard_normal((o.nfree, k))
+    y, ms = b.spmv(x if k > 1 else x[:, 0], reps=3)
+    y = y.reshape(o.nfree, k)
+    for c in range(k):
+        yr = o.spmv(x[:, c])
+        assert np.max(np.abs(y[:, c] - yr)) <= 1e-13 * np.max(np.abs(yr)) * 50
+    b.close()
+
+
+def test_more_rhs_than_one_chunk(mesh2d, gpu_ctx):
+    """11 right-hand sides -> chunks of 8 + 3; every column must equal its single-RHS solve."""
+    from remo3d_amd import solver
+    zs = np.linspace(-0.5, 0.5, 11)
+    src = [([z], [1.0]) for z in zs]
+    ev = [[z + 0.4, z + 6.4] for z in zs]
+    opts = solver.make_opts(preconditioner="local", rtol=1e-12, maxsteps=20000)
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, src, ev, opts)
+    assert rc == 0
+    for i in (0, 7, 8, 10):
+        single, _, rc1 = gpu_ctx.solve_batch(mesh2d, SIGMA3, [src[i]], [ev[i]], opts)
+        assert rc1 == 0
+        assert np.allclose(outs[i], single[0], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_homogeneous_medium_gives_true_resistivity(dim, gpu_ctx):
+    """Physics identity of remo3d.py:285-306: in a homogeneous medium Ra == R for every tool."""
+    from remo3d_amd import solver
+    from remo3d_amd.meshgen import make_mesh
+    R, sigma = 50.0, 0.1
+    mesh = make_mesh(dim, R, [0.0], scale=1.0 if dim == 2 else 3.0, snap_z=[0.4, 6.4, 2.0, 2.5])
+    outs, st, rc = gpu_ctx.solve_batch(mesh, [sigma], [([0.0], [1.0])], [[0.4, 6.4, 2.0, 2.5]],
+                                       solver.make_opts(preconditioner="local", rtol=1e-10, maxsteps=20000))
+    assert rc == 0
+    u = outs[0] / (1.0 if dim == 2 else 2.0)   # half-space model carries twice the potential (worker.py:129)
+    ra_normal = abs(4 * np.pi * 0.4 * 6.4 / 6.0 * (u[1] - u[0]))
+    ra_lateral = abs(4 * np.pi * 2.0 * 2.5 / 0.5 * (u[3] - u[2]))
+    assert abs(ra_normal - 10.0) < 5e-3 and abs(ra_lateral - 10.0) < 5e-3, (ra_normal, ra_lateral)
+
+
+def test_error_paths_fill_nan(mesh2d, gpu_ctx):
+    from remo3d_amd import solver
+    # evaluation point outside the domain -> REMO_ERR_POINT, NaN outputs (worker.py:135-138 convention)
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, [([0.0], [1.0])], [[0.4, 80.0]], solver.make_opts(), raise_on_error=False)
+    assert rc == -4 and np.all(np.isnan(outs[0]))
+    # too few steps -> warning code, finite outputs (the reference is silent, ngsolve_functions.py:50)
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, [([0.0], [1.0])], [[0.4]],
+                                       solver.make_opts(preconditioner="local", rtol=1e-12, maxsteps=5), raise_on_error=False)
+    assert rc == 1 and np.all(np.isfinite(outs[0]))
+    # zero-strength sources are skipped (ngsolve_functions.py:43): all-zero RHS gives u == 0
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, [([0.0], [0.0])], [[0.4]], solver.make_opts(), raise_on_error=False)
+    assert rc == 0 and outs[0][0] == 0.0

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — measurement points per second of the ReMo3D hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the reference's
+3D benchmark model — Examples/Benchmark models/Benchmark model 3, dip 30 deg — logged with a
+normal and a lateral tool (A0.4M6.0N, A2.0M0.5N) at 100 depths per GPU in [5, 20) m, R = 50 m,
+batch_size 5 (=> 40 batches / 200 right-hand sides / 200 measurement points per GPU, computed
+with the build's task builder, pinned against the reference's in tests/golden/tasks_bm3.json).
+Batch meshes are seeded synthetic half-ball meshes with the reference's size field (no Gmsh in
+the image); their sizes (T, n, nnz) are printed in the JSON line.
+
+One "step" = one pass of the hot path over every batch of this rank's share: dof numbering,
+CSR pattern, assembly, multi-RHS Jacobi-PCG, axis evaluation, apparent resistivity — then ONE
+all-reduce of the log slab across ranks (RCCL).  Mesh arrays, sigma and points are resident on
+the device before the timed region (remo_batch_create); mesh generation is excluded, as SURVEY.md
+section 8d defines the point.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torchrun, one rank
+per GPU.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIZES = {"S": 4.0, "M": 2.5, "L": 1.2, "XL": 0.7}   # multiplier on the reference size field
+HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_workload(rank, world, depths_per_gpu, scale, dim=3):
+    from remo3d_amd import geometry, tasks, tools
+    from remo3d_amd.model import Model, default_mesh_provider
+    ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
+    names = ["A0.4M6.0N", "A2.0M0.5N"]
+    m = Model(names)
+    m.set_model_parameters(os.path.join(ex, "Formation_BM3_30.txt"), os.path.join(ex, "Borehole_BM3.txt"), dip=30)
+    m.borehole_model = m._add_points_to_borehole()
+    depths = np.linspace(5.0, 20.0, depths_per_gpu * world, endpoint=False)
+    sim, batches = tasks.build_batches(m.tools, m.sec, depths, 5)
+    mud = np.interp(sim, m.borehole_model[:, 0], m.borehole_model[:, 2])
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    provider = default_mesh_provider(scale=scale, seed=0)
+    work = []
+    t0 = time.time()
+    for bi in range(rank, len(batches), world):
+        b = batches[bi]
+        fg, bh, sigma = geometry.select_data_range(bg, m.formation_model, m.dip_rad, mud[bi], sim[bi], 50.0)
+        mesh = provider(dim, 50.0, b, fg, bh, m.dip_rad)
+        sources, evals, readers = tasks.batch_rhs(b, m.tools)
+        work.append(dict(mesh=mesh, sigma=sigma, sources=sources, evals=evals, readers=readers))
+    return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=names)
+
+
+def cpu_baseline(work, rtol, budget_rhs=1):
+    """The oracle (scalar C port of the same algorithm) on the first batch, first RHS(s): assembly
+    + Jacobi-PCG + evaluation on ONE host core.  Reported beside the GPU number, never the target."""
+    from oracle.fem_oracle import solve_batch
+    w = work[0]
+    k = min(budget_rhs, len(w["sources"]))
+    src_ptr = [0]; sz = []; sI = []; ev_ptr = [0]; ez = []
+    for i in range(k):
+        z, I = w["sources"][i]
+        sz += list(z); sI += list(I); src_ptr.append(len(sz))
+        ez += list(w["evals"][i]); ev_ptr.append(len(ez))
+    t0 = time.time()
+    out, rc, st = solve_batch(w["mesh"], w["sigma"], src_ptr, sz, sI, ev_ptr, ez, condense=True, rtol=rtol, maxit=1000)
+    dt = time.time() - t0
+    pts = sum(len(w["readers"][i]) for i in range(k))
+    return dict(value=pts / dt, unit="points/s", cores=1, kind="port",
+                sample=f"batch 0 of the workload, first {k} of {len(w['sources'])} right-hand sides ({pts} points): "
+                       f"oracle/fem_oracle.c assembly + Jacobi-PCG (rtol {rtol:g}, {st['iterations']} steps) in {dt:.1f} s; "
+                       "NGSolve is not installable here, so this is the build's scalar C restatement, not the reference binary"), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", default="M", choices=list(SIZES))
+    ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU")
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--maxsteps", type=int, default=1000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from remo3d_amd import solver, sweep, tasks
+    dist_on = False
+    if world > 1:
+        import torch
+        dist_on = sweep.init_from_env()
+        torch.cuda.set_device(local)
+
+    wl = build_workload(rank, world, args.depths, SIZES[args.size])
+    work = wl["work"]
+    ctx = solver.Context(local)
+    opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
+                            time_kernels=not args.no_events)
+    resident = [ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for w in work]
+    n_tools = len(wl["names"])
+
+    def one_step():
+        slab = np.zeros((len(wl["depths"]), n_tools))
+        agg = dict(spmv_ms=0.0, spmv_launches=0, spmv_bytes_total=0.0, pcg_steps=0, not_converged=0, ms_symbolic=0.0, ms_assemble=0.0,
+                   ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0)
+        for w, b in zip(work, resident):
+            rc = b.run(opts, raise_on_error=False)
+            st = b.stats
+            if rc < 0:
+                for rd in w["readers"]:
+                    for (di, ti, K, o, m) in rd:
+                        slab[di, ti] = np.nan
+                continue
+            agg["not_converged"] += int(rc == 1)
+            outs = b.fetch()
+            for u, rd in zip(outs, w["readers"]):
+                for (di, ti, K, o, m) in rd:
+                    slab[di, ti] = tasks.apparent_resistivity(u[o:o + m], m, K, 3)
+            agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
+            agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
+            agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
+            for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
+                agg[k] += st[k]
+            agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]
+        slab = sweep.combine(slab)   # the ONE collective of the path: all-reduce of the log slab
+        return slab, agg
+
+    def sync():
+        if dist_on:
+            import torch
+            sweep.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        slab, agg = one_step()
+    sync()
+    dt = sweep.max_over_ranks(time.time() - t0)
+
+    n_points = len(wl["depths"]) * n_tools
+    value = n_points * args.steps / dt
+    if rank != 0:
+        return
+    ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
+    roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=None,
+                    kernel="k_spmm (CSR SpMM, fp64, k=5 interleaved RHS)", launches=int(agg["spmv_launches"]),
+                    avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)")
+    out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload=f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
+                           batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
+                           mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
+                           maxsteps=args.maxsteps, preconditioner="jacobi", max_pcg_iterations=int(agg["max_it"]),
+                           batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
+               roofline=roofline,
+               breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],
+                                          eval=agg["ms_eval"], pcg_steps=int(agg["pcg_steps"]), mesh_generation_excluded_s=wl["mesh_s"]))
+    if not args.no_cpu:
+        cb, ref_out = cpu_baseline(work, args.rtol)
+        out["cpu_baseline"] = cb
+        got = resident[0].fetch()[0]
+        out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got - ref_out) / np.abs(ref_out)))
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,12 +14,14 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/remo3d_hip.h"
 #include "fem_p3.h"
 #include "kernels.h"
 #include "symbolic.h"
+#include "symbolic_gpu.h"
 
 using namespace remo;
 
@@ -50,8 +52,7 @@ struct remo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    char *arena = nullptr;
-    size_t arena_cap = 0, arena_off = 0;
+    Arena ar;
     double *d_M2 = nullptr, *d_M3 = nullptr;
     PcgProgress *progress = nullptr;  // mapped, coherent host memory
     PcgProgress *progress_dev = nullptr;
@@ -60,23 +61,17 @@ struct remo_ctx {
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> spmv_ev;
 
-    template <class T> T *take(size_t count) {
-        const size_t bytes = align_up(count * sizeof(T));
-        if (arena_off + bytes > arena_cap) throw std::runtime_error("device arena exhausted (internal sizing error)");
-        T *p = reinterpret_cast<T *>(arena + arena_off);
-        arena_off += bytes;
-        return p;
-    }
+    template <class T> T *take(size_t count) { return ar.lo<T>(count); }
     void reserve(size_t bytes) {
-        arena_off = 0;
-        if (bytes <= arena_cap) return;
+        ar.reset();
+        if (bytes <= ar.cap) return;
         HIP_TRY(hipStreamSynchronize(stream));
-        if (arena) HIP_TRY(hipFree(arena));
-        arena = nullptr;
-        arena_cap = 0;
-        const size_t want = bytes + bytes / 4;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&arena), want));
-        arena_cap = want;
+        if (ar.base) HIP_TRY(hipFree(ar.base));
+        ar.base = nullptr;
+        ar.cap = 0;
+        const size_t want = align_up(bytes + bytes / 4, 4096);  // the top-down end must stay aligned too
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ar.base), want));
+        ar.cap = want;
     }
     void ensure_progress(int len) {
         if (len <= progress_len) return;
@@ -91,42 +86,26 @@ struct remo_ctx {
 };
 
 struct remo_batch {
-    // host copy of the mesh (the numbering pass runs on the host cores)
     int dim = 0;
-    std::vector<double> coords;
-    std::vector<int32_t> conn, mat, bconn;
-    std::vector<uint8_t> bdir;
-    std::vector<double> sigma;
+    int64_t nv = 0, nt = 0, nbf = 0;
+    int n_mat = 0;
     // points: per chunk [sources..., evals...]
     int n_rhs = 0;
     std::vector<int32_t> src_ptr, eval_ptr;
     std::vector<double> src_z, src_I, eval_z;
-    // resident device inputs
+    // resident device inputs (everything the path reads is in HBM before remo_batch_run)
     double *d_coords = nullptr, *d_sigma = nullptr;
-    int32_t *d_mat = nullptr;
+    int32_t *d_mat = nullptr, *d_conn = nullptr, *d_bconn = nullptr;
+    uint8_t *d_bdir = nullptr;
     // last system (pointers into the context arena; valid until the next run on the context)
     bool has_system = false;
-    Symbolic sym;
+    DeviceSymbolic sym;
     CsrView A{};
     double *d_val = nullptr, *d_dinv = nullptr;
     std::vector<double> u_out;
 };
 
 namespace {
-
-remo_mesh_t mesh_view(const remo_batch &b) {
-    remo_mesh_t m;
-    m.dim = b.dim;
-    m.n_nodes = int64_t(b.coords.size()) / b.dim;
-    m.coords = b.coords.data();
-    m.n_elems = int64_t(b.mat.size());
-    m.conn = b.conn.data();
-    m.mat = b.mat.data();
-    m.n_bfacets = int64_t(b.bdir.size());
-    m.bconn = b.bconn.data();
-    m.bdirichlet = b.bdir.data();
-    return m;
-}
 
 int fail(remo_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -280,7 +259,7 @@ void remo_ctx_destroy(remo_ctx_t *ctx) {
     for (auto &ev : ctx->spmv_ev) hipEventDestroy(ev);
     for (auto &ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
-    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->ar.base) hipFree(ctx->ar.base);
     if (ctx->d_M2) hipFree(ctx->d_M2);
     if (ctx->d_M3) hipFree(ctx->d_M3);
     if (ctx->d_err) hipFree(ctx->d_err);
@@ -300,62 +279,56 @@ int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, c
     if (mesh->dim != 2 && mesh->dim != 3) return fail(ctx, REMO_ERR_ARG, "dim must be 2 or 3");
     if (mesh->n_nodes <= 0 || mesh->n_elems <= 0 || !mesh->coords || !mesh->conn || !mesh->mat)
         return fail(ctx, REMO_ERR_ARG, "empty mesh");
+    if (mesh->n_bfacets < 0 || (mesh->n_bfacets > 0 && (!mesh->bconn || !mesh->bdirichlet)))
+        return fail(ctx, REMO_ERR_ARG, "boundary arrays missing");
+    if (mesh->n_nodes >= (int64_t(1) << 31) || mesh->n_elems >= (int64_t(1) << 27)) return fail(ctx, REMO_ERR_ARG, "mesh too large");
     if (src_ptr[0] != 0 || eval_ptr[0] != 0) return fail(ctx, REMO_ERR_ARG, "src_ptr / eval_ptr must start at 0");
     for (int k = 0; k < n_rhs; ++k)
         if (src_ptr[k + 1] < src_ptr[k] || eval_ptr[k + 1] < eval_ptr[k]) return fail(ctx, REMO_ERR_ARG, "src_ptr / eval_ptr not monotone");
     if ((src_ptr[n_rhs] > 0 && (!src_z || !src_I)) || (eval_ptr[n_rhs] > 0 && !eval_z)) return fail(ctx, REMO_ERR_ARG, "point arrays missing");
+    const int dim = mesh->dim, nb = dim + 1;
+    for (int64_t i = 0; i < mesh->n_nodes * dim; ++i)
+        if (!std::isfinite(mesh->coords[i])) return fail(ctx, REMO_ERR_MESH, "non-finite coordinate");
+    for (int i = 0; i < n_mat; ++i)
+        if (!(sigma[i] > 0.0) || !std::isfinite(sigma[i])) return fail(ctx, REMO_ERR_ARG, "sigma must be positive and finite");
     remo_batch *b = nullptr;
     try {
         HIP_TRY(hipSetDevice(ctx->device));
         b = new remo_batch();
-        const int dim = mesh->dim, nb = dim + 1;
-        b->dim = dim;
-        b->coords.assign(mesh->coords, mesh->coords + mesh->n_nodes * dim);
-        b->conn.assign(mesh->conn, mesh->conn + mesh->n_elems * nb);
-        b->mat.assign(mesh->mat, mesh->mat + mesh->n_elems);
-        if (mesh->n_bfacets > 0) {
-            if (!mesh->bconn || !mesh->bdirichlet) { delete b; return fail(ctx, REMO_ERR_ARG, "boundary arrays missing"); }
-            b->bconn.assign(mesh->bconn, mesh->bconn + mesh->n_bfacets * dim);
-            b->bdir.assign(mesh->bdirichlet, mesh->bdirichlet + mesh->n_bfacets);
-        }
-        b->sigma.assign(sigma, sigma + n_mat);
+        b->dim = dim; b->nv = mesh->n_nodes; b->nt = mesh->n_elems; b->nbf = mesh->n_bfacets; b->n_mat = n_mat;
         b->n_rhs = n_rhs;
         b->src_ptr.assign(src_ptr, src_ptr + n_rhs + 1);
         b->eval_ptr.assign(eval_ptr, eval_ptr + n_rhs + 1);
         b->src_z.assign(src_z, src_z + src_ptr[n_rhs]);
         b->src_I.assign(src_I, src_I + src_ptr[n_rhs]);
         b->eval_z.assign(eval_z, eval_z + eval_ptr[n_rhs]);
-        for (double c : b->coords)
-            if (!std::isfinite(c)) { delete b; return fail(ctx, REMO_ERR_MESH, "non-finite coordinate"); }
-        for (double sg : b->sigma)
-            if (!(sg > 0.0) || !std::isfinite(sg)) { delete b; return fail(ctx, REMO_ERR_ARG, "sigma must be positive and finite"); }
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_coords), sizeof(double) * b->coords.size()));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_mat), sizeof(int32_t) * b->mat.size()));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->d_sigma), sizeof(double) * b->sigma.size()));
-        HIP_TRY(hipMemcpyAsync(b->d_coords, b->coords.data(), sizeof(double) * b->coords.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(b->d_mat, b->mat.data(), sizeof(int32_t) * b->mat.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(b->d_sigma, b->sigma.data(), sizeof(double) * b->sigma.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        hipStream_t s = ctx->stream;
+        auto up = [&](auto **dst, const auto *src, size_t count) {
+            using T = std::remove_const_t<std::remove_pointer_t<decltype(src)>>;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), sizeof(T) * (count ? count : 1)));
+            if (count) HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, s));
+        };
+        up(&b->d_coords, mesh->coords, size_t(b->nv) * dim);
+        up(&b->d_conn, mesh->conn, size_t(b->nt) * nb);
+        up(&b->d_mat, mesh->mat, size_t(b->nt));
+        up(&b->d_sigma, sigma, size_t(n_mat));
+        up(&b->d_bconn, mesh->bconn, size_t(b->nbf) * dim);
+        up(&b->d_bdir, mesh->bdirichlet, size_t(b->nbf));
+        HIP_TRY(hipStreamSynchronize(s));
         b->u_out.assign(size_t(eval_ptr[n_rhs]), std::nan(""));
         *out = b;
         return REMO_OK;
     } catch (const std::exception &ex) {
-        if (b) {
-            if (b->d_coords) hipFree(b->d_coords);
-            if (b->d_mat) hipFree(b->d_mat);
-            if (b->d_sigma) hipFree(b->d_sigma);
-            delete b;
-        }
+        remo_batch_destroy(ctx, b);
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
 }
 
 void remo_batch_destroy(remo_ctx_t *ctx, remo_batch_t *b) {
     if (!b) return;
-    if (ctx) hipSetDevice(ctx->device);
-    if (b->d_coords) hipFree(b->d_coords);
-    if (b->d_mat) hipFree(b->d_mat);
-    if (b->d_sigma) hipFree(b->d_sigma);
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (void *p : {(void *)b->d_coords, (void *)b->d_mat, (void *)b->d_sigma, (void *)b->d_conn, (void *)b->d_bconn, (void *)b->d_bdir})
+        if (p) (void)hipFree(p);
     delete b;
 }
 
@@ -374,18 +347,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
     try {
         HIP_TRY(hipSetDevice(ctx->device));
         hipStream_t s = ctx->stream;
-        // ---- numbering + pattern (host) -------------------------------------------------
-        std::string err;
-        const remo_mesh_t mv = mesh_view(*b);
-        int rc = build_symbolic(mv, o.condense != 0, true, b->sym, err);
-        if (rc != REMO_OK) return fail(ctx, rc, err);
-        const Symbolic &sy = b->sym;
-        st->ms_symbolic = now_ms() - t_start;
-        st->n_dof = sy.ndof; st->n_free = sy.nfree; st->nnz = sy.nnz; st->n_edges = sy.ne; st->n_faces = sy.nf;
-        st->n_rhs = b->n_rhs;
-        const int dim = sy.dim, nb = dim + 1, N = sy.nld_full;
-        const int NT = (dim == 2) ? 9 : 6;
-        const int64_t n = sy.nfree, nt = sy.nt;
+        const int dim = b->dim, N = (dim == 2) ? 10 : 20, NT = (dim == 2) ? 9 : 6;
+        const int64_t nt = b->nt, nv = b->nv;
         const int kmax = std::min<int>(b->n_rhs, REMO_MAX_RHS);
 
         // ---- points of all RHS, chunk by chunk: [sources..., evals...] -------------------
@@ -408,22 +371,23 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         for (double z : pz)
             if (!std::isfinite(z)) return fail(ctx, REMO_ERR_POINT, "non-finite point coordinate");
 
-        // ---- device arena -----------------------------------------------------------------
-        size_t need = 0;
-        auto add = [&](size_t bytes) { need += align_up(bytes); };
-        add(sizeof(int32_t) * nt * nb); add(sizeof(int32_t) * nt * N); add(sizeof(int32_t) * (n + 1) * 2);
-        add(sizeof(int32_t) * sy.nnz); add(sizeof(uint32_t) * sy.adj.size()); add(sizeof(double) * nt * NT);
-        add(sizeof(double) * sy.nnz); add(sizeof(double) * n);
-        for (int i = 0; i < 5; ++i) add(sizeof(double) * n * kmax);  // f x r p q
-        add(sizeof(double) * kMaxPartialBlocks * 8 * 3); add(sizeof(double) * 8);
-        add(sizeof(double) * npts * 2); add(sizeof(int32_t) * npts * 2); add(sizeof(double) * npts * (N + 2));
-        ctx->reserve(need + 4096);
-        int32_t *d_conn = ctx->take<int32_t>(nt * nb);
-        int32_t *d_eldof = ctx->take<int32_t>(nt * N);
-        int32_t *d_rowptr = ctx->take<int32_t>(n + 1);
-        int32_t *d_adjptr = ctx->take<int32_t>(n + 1);
-        int32_t *d_col = ctx->take<int32_t>(sy.nnz);
-        uint32_t *d_adj = ctx->take<uint32_t>(sy.adj.size());
+        // ---- device arena: numbering scratch + upper bounds of everything numeric ---------
+        const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
+        size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
+        need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax));
+        need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
+        ctx->reserve(need);
+
+        // ---- dof numbering + CSR pattern (device) ------------------------------------------
+        std::string err;
+        DeviceSymbolic &sy = b->sym;
+        int rc = build_symbolic_gpu(ctx->ar, s, dim, nv, nt, b->d_conn, b->nbf, b->d_bconn, b->d_bdir, o.condense != 0, ctx->d_err, sy, err);
+        if (rc != REMO_OK) return fail(ctx, rc, err);
+        st->ms_symbolic = now_ms() - t_start;
+        st->n_dof = sy.ndof; st->n_free = sy.nfree; st->nnz = sy.nnz; st->n_edges = sy.ne; st->n_faces = sy.nf;
+        st->n_rhs = b->n_rhs;
+        const int64_t n = sy.nfree;
+
         double *d_C = ctx->take<double>(nt * NT);
         double *d_val = ctx->take<double>(sy.nnz);
         double *d_dinv = ctx->take<double>(n);
@@ -435,9 +399,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
         buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
         buf.rz0 = ctx->take<double>(8);
-        double *d_pz = ctx->take<double>(npts), *d_pI = ctx->take<double>(npts);
-        int32_t *d_prhs = ctx->take<int32_t>(npts), *d_found = ctx->take<int32_t>(npts);
-        double *d_phi = ctx->take<double>(size_t(npts) * N), *d_fint = ctx->take<double>(npts), *d_out = ctx->take<double>(npts);
+        double *d_pz = ctx->take<double>(npts + 1), *d_pI = ctx->take<double>(npts + 1);
+        int32_t *d_prhs = ctx->take<int32_t>(npts + 1), *d_found = ctx->take<int32_t>(npts + 1);
+        double *d_phi = ctx->take<double>(size_t(npts + 1) * N), *d_fint = ctx->take<double>(npts + 1), *d_out = ctx->take<double>(npts + 1);
         ctx->ensure_progress(o.maxsteps + 2);
         buf.progress = ctx->progress_dev;
         buf.progress_len = ctx->progress_len;
@@ -447,36 +411,29 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             for (size_t i = old; i < ctx->spmv_ev.size(); ++i) HIP_TRY(hipEventCreate(&ctx->spmv_ev[i]));
         }
 
-        // ---- uploads ----------------------------------------------------------------------
+        // ---- small uploads (points) ---------------------------------------------------------
         HIP_TRY(hipEventRecord(ctx->ev[0], s));
         HIP_TRY(hipMemsetAsync(ctx->d_err, 0, sizeof(int32_t), s));
-        HIP_TRY(hipMemcpyAsync(d_conn, sy.conn.data(), sizeof(int32_t) * nt * nb, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_eldof, sy.eldof.data(), sizeof(int32_t) * nt * N, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_rowptr, sy.rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_adjptr, sy.adjptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_col, sy.col.data(), sizeof(int32_t) * sy.nnz, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_adj, sy.adj.data(), sizeof(uint32_t) * sy.adj.size(), hipMemcpyHostToDevice, s));
+        std::vector<int32_t> found_init(npts, INT_MAX);
         if (npts > 0) {
             HIP_TRY(hipMemcpyAsync(d_pz, pz.data(), sizeof(double) * npts, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_pI, pI.data(), sizeof(double) * npts, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_prhs, prhs.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_found, found_init.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
         }
         HIP_TRY(hipEventRecord(ctx->ev[1], s));
 
         // ---- assembly ---------------------------------------------------------------------
         const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
-        launch_metric_terms(dim, nt, b->d_coords, d_conn, b->d_mat, b->d_sigma, int(b->sigma.size()), d_C, ctx->d_err, s);
-        launch_assemble(dim, sy.condense, n, d_rowptr, d_col, d_adjptr, d_adj, d_eldof, d_C, d_M, d_val, d_dinv, s);
+        launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
+        launch_assemble(dim, sy.condense, n, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
 
         // ---- point location + shapes (all points at once) ---------------------------------
         if (npts > 0) {
-            std::vector<int32_t> init(npts, INT_MAX);
-            HIP_TRY(hipMemcpyAsync(d_found, init.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // init is a stack-lifetime buffer
             for (int q0 = 0; q0 < npts; q0 += kMaxPoints)
-                launch_locate(dim, nt, b->d_coords, d_conn, std::min(kMaxPoints, npts - q0), d_pz + q0, d_found + q0, s);
-            launch_point_shapes(dim, npts, d_pz, d_found, b->d_coords, d_conn, d_phi, ctx->d_err, s);
+                launch_locate(dim, nt, b->d_coords, sy.conn, std::min(kMaxPoints, npts - q0), d_pz + q0, d_found + q0, s);
+            launch_point_shapes(dim, npts, d_pz, d_found, b->d_coords, sy.conn, d_phi, ctx->d_err, s);
         }
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         int32_t h_err = 0;
@@ -485,7 +442,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
 
-        b->A = CsrView{n, sy.nnz, d_rowptr, d_col, d_val};
+        b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->has_system = true;
@@ -509,21 +466,21 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             HIP_TRY(hipEventRecord(ctx->ev[4], s));
             HIP_TRY(hipMemsetAsync(d_f, 0, sizeof(double) * n * k, s));
             if (nq > 0)
-                launch_build_rhs(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, d_eldof, d_C, d_M, k,
+                launch_build_rhs(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, sy.eldof, d_C, d_M, k,
                                  d_f, d_fint + q0, s);
             HIP_TRY(hipEventRecord(ctx->ev[5], s));
             ChunkResult cr = run_pcg(ctx, b->A, k, d_f, buf, o, st, ev_used);
             HIP_TRY(hipEventRecord(ctx->ev[6], s));
             if (nq > 0)
-                launch_eval(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, d_eldof, d_C, d_M, k, buf.x,
+                launch_eval(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, sy.eldof, d_C, d_M, k, buf.x,
                             d_fint + q0, d_out + q0, s);
             HIP_TRY(hipEventRecord(ctx->ev[7], s));
             if (nq > 0) HIP_TRY(hipMemcpyAsync(h_out.data() + q0, d_out + q0, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             float e1 = 0, e2 = 0, e3 = 0;
-            hipEventElapsedTime(&e1, ctx->ev[4], ctx->ev[5]);
-            hipEventElapsedTime(&e2, ctx->ev[5], ctx->ev[6]);
-            hipEventElapsedTime(&e3, ctx->ev[6], ctx->ev[7]);
+            (void)hipEventElapsedTime(&e1, ctx->ev[4], ctx->ev[5]);
+            (void)hipEventElapsedTime(&e2, ctx->ev[5], ctx->ev[6]);
+            (void)hipEventElapsedTime(&e3, ctx->ev[6], ctx->ev[7]);
             ms_eval += e1 + e3;
             ms_solve += e2;
             if (!cr.finite) return fail(ctx, REMO_ERR_NUMERIC, "non-finite residual in PCG");
@@ -537,16 +494,16 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         for (int q = 0; q < npts; ++q)
             if (eval_slot[q] >= 0) b->u_out[eval_slot[q]] = h_out[q];
         float m = 0;
-        hipEventElapsedTime(&m, ctx->ev[0], ctx->ev[1]); st->ms_h2d = m;
-        hipEventElapsedTime(&m, ctx->ev[1], ctx->ev[2]); st->ms_assemble = m;
-        hipEventElapsedTime(&m, ctx->ev[2], ctx->ev[3]); st->ms_eval = m + ms_eval;
+        (void)hipEventElapsedTime(&m, ctx->ev[0], ctx->ev[1]); st->ms_h2d = m;
+        (void)hipEventElapsedTime(&m, ctx->ev[1], ctx->ev[2]); st->ms_assemble = m;
+        (void)hipEventElapsedTime(&m, ctx->ev[2], ctx->ev[3]); st->ms_eval = m + ms_eval;
         st->ms_solve = ms_solve;
         st->spmv_bytes = 12.0 * double(sy.nnz) + 4.0 * double(n) + 16.0 * double(kmax) * double(n);
         if (o.time_kernels) {
             double sum = 0;
             for (size_t i = 0; i + 1 < ev_used; i += 2) {
                 float e = 0;
-                hipEventElapsedTime(&e, ctx->spmv_ev[i], ctx->spmv_ev[i + 1]);
+                (void)hipEventElapsedTime(&e, ctx->spmv_ev[i], ctx->spmv_ev[i + 1]);
                 sum += e;
             }
             st->spmv_ms = sum;
@@ -589,10 +546,10 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int
     if (!b || !b->has_system) return fail(ctx, REMO_ERR_ARG, "no assembled system on this batch (run it first)");
     try {
         HIP_TRY(hipSetDevice(ctx->device));
-        const Symbolic &sy = b->sym;
-        if (rowptr) std::memcpy(rowptr, sy.rowptr.data(), sizeof(int32_t) * (sy.nfree + 1));
-        if (col) std::memcpy(col, sy.col.data(), sizeof(int32_t) * sy.nnz);
-        if (freeid) std::memcpy(freeid, sy.freeid.data(), sizeof(int32_t) * sy.ndof);
+        const DeviceSymbolic &sy = b->sym;
+        if (rowptr) HIP_TRY(hipMemcpy(rowptr, sy.rowptr, sizeof(int32_t) * (sy.nfree + 1), hipMemcpyDeviceToHost));
+        if (col) HIP_TRY(hipMemcpy(col, sy.col, sizeof(int32_t) * sy.nnz, hipMemcpyDeviceToHost));
+        if (freeid) HIP_TRY(hipMemcpy(freeid, sy.freeid, sizeof(int32_t) * sy.ndof, hipMemcpyDeviceToHost));
         if (val) HIP_TRY(hipMemcpy(val, b->d_val, sizeof(double) * sy.nnz, hipMemcpyDeviceToHost));
         if (dinv) HIP_TRY(hipMemcpy(dinv, b->d_dinv, sizeof(double) * sy.nfree, hipMemcpyDeviceToHost));
         return REMO_OK;
@@ -618,14 +575,14 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         float ms = 0;
-        hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
         if (ms_avg) *ms_avg = double(ms) / reps;
         HIP_TRY(hipMemcpy(y, dy, sizeof(double) * n * k, hipMemcpyDeviceToHost));
-        hipFree(dx); hipFree(dy);
+        (void)hipFree(dx); (void)hipFree(dy);
         return REMO_OK;
     } catch (const std::exception &ex) {
-        if (dx) hipFree(dx);
-        if (dy) hipFree(dy);
+        if (dx) (void)hipFree(dx);
+        if (dy) (void)hipFree(dy);
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
 }

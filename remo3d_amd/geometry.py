@@ -1,0 +1,135 @@
+"""Windowing of the global borehole / formation model to the simulation sphere of one batch:
+the build's own restatement of remo3d/gmsh_functions.py:10-174 (SelectGmshDataRange and its two
+helpers).  Output frame: depth relative to the batch's combined depth, z positive downwards.
+
+Quirks of the reference that are kept because they define its results (pinned by
+tests/golden/windows_*.json, generated from the reference in this container):
+  * the borehole polyline keeps one extra sample on each side of the window (3-tap dilation);
+  * in dipping models the borehole window is a slab |z| < R, not a sphere;
+  * layers are kept when either boundary is closer than 0.99 R to the window centre, measured
+    perpendicular to the (dipping) boundary; flushed zones that do not reach into that radius are
+    merged into the undisturbed zone;
+  * the first / last layer is stretched to +-1.01 R (times sqrt(1 + tan^2 dip) when dipping).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _segment_circle_hit(p1, p2, radius):
+    """Intersection of segment p1->p2 (rows are (z, r)) with the circle z^2 + r^2 = radius^2 that
+    lies strictly inside the segment (gmsh_functions.py:12-25)."""
+    x1, y1 = p1[1], p1[0]
+    x2, y2 = p2[1], p2[0]
+    dx, dy = x2 - x1, y2 - y1
+    dr2 = dx * dx + dy * dy
+    D = x1 * y2 - x2 * y1
+    disc = radius ** 2 * dr2 - D ** 2
+    for sign in (-1, 1):
+        x = (D * dy + sign * np.sign(dy) * dx * np.sqrt(disc)) / dr2
+        y = (-D * dx + sign * np.abs(dy) * np.sqrt(disc)) / dr2
+        p = np.array([y, x])
+        t = np.dot(p1 - p2, p1 - p)
+        if 0 < t < np.dot(p1 - p2, p1 - p2):
+            return p
+    return None
+
+
+def window_borehole(borehole_geometry, dip, depth, R):
+    """Local borehole wall polyline [(z, radius)] clipped to the domain (gmsh_functions.py:10-90)."""
+    bg = np.asarray(borehole_geometry, dtype=float)
+    if bg.shape[0] == 2:
+        loc = bg.copy()
+    else:
+        if dip == 0:
+            inside = (bg[:, 0] - depth) ** 2 + bg[:, 1] ** 2 < R ** 2
+        else:
+            inside = np.abs(bg[:, 0] - depth) < R
+        grown = inside.copy()
+        grown[:-1] |= inside[1:]
+        grown[1:] |= inside[:-1]
+        loc = bg[grown, :].copy()
+    loc[:, 0] -= depth
+
+    def on_or_in(z, r):
+        if dip == 0:
+            q = z * z + r * r
+            return (q == R * R), (q < R * R)
+        return (abs(z) == R), (abs(z) < R)
+
+    for end in (0, -1):
+        nxt = 1 if end == 0 else -2
+        z, r = loc[end]
+        on, inn = on_or_in(z, r)
+        sgn = -1.0 if end == 0 else 1.0
+        if on:
+            continue
+        if inn:  # extend straight up / down to the domain boundary at the same radius
+            if dip == 0:
+                omega = np.arccos(r / R)
+                new = np.array([sgn * np.sin(omega) * R, r])
+            else:
+                new = np.array([sgn * R, r])
+            loc = np.vstack((new, loc)) if end == 0 else np.vstack((loc, new))
+        else:    # pull the outside point back onto the boundary
+            if dip == 0:
+                loc[end, :] = _segment_circle_hit(loc[end, :], loc[nxt, :], R)
+            else:
+                a = abs(loc[end, 0]) - R
+                b = R - sgn * loc[nxt, 0]
+                loc[end, :] = [sgn * R, (b * loc[end, 1] + a * loc[nxt, 1]) / (a + b)]
+    return loc
+
+
+def window_formation(formation_parameters, dip, depth, R, active_geometry_window=0.99):
+    """Local layer table [(top, bottom, fz_radius)] and the resistivity list in material order
+    (gmsh_functions.py:92-165)."""
+    fp = np.asarray(formation_parameters, dtype=float)
+    active = R * active_geometry_window
+    loc = fp.copy()
+    loc[:, :2] -= depth
+    if dip == 0:
+        a = 0.0
+        dist = np.abs(loc[:, :2])
+    else:
+        a = np.tan(dip)
+        dist = np.abs(loc[:, :2]) / np.sqrt(a * a + 1.0)
+    layers = loc[np.any(dist < active, axis=1), :]
+
+    has_fz = ~np.isnan(layers[:, 2])
+    if dip == 0:
+        xs = np.repeat(layers[has_fz, 2][:, None], 2, axis=1)
+        ys = layers[has_fz, :2]
+    else:
+        xs = np.repeat(layers[has_fz, 2][:, None], 4, axis=1)
+        xs[:, :2] *= -1
+        ys = a * xs + np.hstack([layers[has_fz, :2], layers[has_fz, :2]])
+    reach = np.any(np.sqrt(xs ** 2 + ys ** 2) < active, axis=1)
+    drop = has_fz.copy()
+    drop[has_fz] = ~reach
+
+    model = layers.copy()
+    with_res = fp.shape[1] == 5
+    if with_res:
+        model[drop, 4] = model[drop, 3]
+        model[drop, 2:4] = np.nan
+    else:
+        model[drop, 2] = np.nan
+    stretch = R * 1.01 if dip == 0 else R * np.sqrt(a * a + 1.0) * 1.01
+    if model[0, 0] > -stretch:
+        model[0, 0] = -stretch
+    if model[-1, 1] < stretch:
+        model[-1, 1] = stretch
+    if not with_res:
+        return model
+    res = model[:, 3:5].ravel()
+    return model[:, :3], res[~np.isnan(res)]
+
+
+def select_data_range(borehole_geometry, formation_parameters, dip, mud_resistivity, depth, R, active_geometry_window=0.99):
+    """(local_formation_geometry, local_borehole_geometry, sigma) with sigma = [1/Rm] + 1/R_zones
+    (gmsh_functions.py:168-174); the order of sigma is the material numbering of the mesh."""
+    bh = window_borehole(borehole_geometry, dip, depth, R)
+    fg, res = window_formation(formation_parameters, dip, depth, R, active_geometry_window)
+    sigma = [1.0 / mud_resistivity] + list(1.0 / res)
+    return fg, bh, sigma

@@ -1,0 +1,288 @@
+"""`Model`: the public face of ReMo3D (remo3d/remo3d.py class Model, lines 23-1147) on top of the
+MI355X library.  Same constructor, same `compute_synthetic_logs(...)` keyword arguments and
+defaults, same `logs` dictionary (tool -> [n_depths, 2] array of depth and apparent resistivity),
+same `Results_<n>.txt` layout.
+
+What differs, by design:
+  * the MPI worker farm (remo3d.py:552-599, 809-865) is gone: one process drives one GPU; under
+    `torchrun` every rank takes a block-cyclic share of the batches and the logs are combined
+    with one RCCL all-reduce of the [n_depths, n_tools] slab (sweep.py);
+  * Gmsh / Netgen are not available: batch meshes come from `mesh_provider` (default: the seeded
+    in-repo mesher, meshgen.make_mesh, with the reference's size field); a provider that reads
+    real MSH 2.2 files can be plugged in;
+  * there is no CPU solver behind it: without libremo3d_hip.so and a GPU, construction of the
+    solver context raises.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import time
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from . import geometry, meshgen, tasks, tools as tools_mod
+
+CONVERSION = {"M": 1.0, "DM": 0.1, "CM": 0.01, "MM": 0.001, "IN": 0.0254, "FT": 0.3048}
+
+
+def default_mesh_provider(scale: float = 1.0, seed: int = 0) -> Callable:
+    """Batch mesh factory with a cache keyed on the electrode pattern: the point cloud depends only
+    on the current-electrode offsets of the batch, the material map on the windowed model."""
+    cache: Dict[tuple, meshgen.Mesh] = {}
+
+    def provider(dim, domain_radius, batch, local_formation_geometry, local_borehole_geometry, dip_rad):
+        cur = batch.electrodes[0, batch.electrodes[1, :] != 0]
+        pot = batch.electrodes[0, batch.electrodes[1, :] == 0]
+        key = (dim, float(domain_radius), tuple(np.round(cur, 4)), tuple(np.round(pot, 4)), float(scale), seed)
+        base = cache.get(key)
+        if base is None:
+            base = meshgen.make_mesh(dim, domain_radius, sources_z=list(cur), scale=scale, seed=seed,
+                                     snap_z=[z for z in pot if abs(z) < domain_radius])
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = base
+        fn = meshgen.layered_material_fn(dim, local_formation_geometry, local_borehole_geometry, dip_rad)
+        mat = fn(base.coords[base.conn].mean(1)).astype(np.int32)
+        return meshgen.Mesh(dim, base.coords, base.conn, mat, base.bconn, base.bdirichlet, base.meta)
+
+    return provider
+
+
+class Model:
+    conversion_table = CONVERSION
+
+    def __init__(self, tools, force_single_electrode_configuration=True):
+        self.tools, self.sec = self.set_tools_parameters(tools, force_single_electrode_configuration=force_single_electrode_configuration)
+        self.formation_model = None
+        self.borehole_model = None
+        self.dip_deg = None
+        self.dip_rad = None
+        self.cpu_workers = None
+        self.gpu_workers = None
+        self.ctx = None
+        self.logs = None
+        self.timing = {}
+
+    # -- complete procedure (remo3d.py:65-174) ---------------------------------------------------
+    @classmethod
+    def compute_synthetic_logs(cls, tools, measurement_depths, formation_model, borehole_model,
+                               force_single_electrode_configuration=True, formation_units=["M", "M", "M"],
+                               borehole_geometry_type="diameter", borehole_units=["M", "M"], dip=0, cpu_workers=4,
+                               gpu_workers=0, domain_radius=50, batch_size=5, mesh_generator="auto",
+                               preconditioner="multigrid", condense=True, **extensions):
+        model = cls(tools, force_single_electrode_configuration=force_single_electrode_configuration)
+        model.set_model_parameters(formation_model, borehole_model, borehole_geometry_type=borehole_geometry_type, dip=dip)
+        model.initialize_workers(cpu_workers=cpu_workers, gpu_workers=gpu_workers)
+        model.simulate_logs(measurement_depths, domain_radius=domain_radius, batch_size=batch_size, mesh_generator=mesh_generator,
+                            preconditioner=preconditioner, condense=condense, **extensions)
+        model.shutdown_workers()
+        return model
+
+    # -- tools (remo3d.py:178-321) ---------------------------------------------------------------
+    def set_tools_parameters(self, tools, force_single_electrode_configuration=True):
+        return tools_mod.tool_tables(tools, force_single_electrode_configuration)
+
+    # -- model (remo3d.py:344-548) ---------------------------------------------------------------
+    def set_model_parameters(self, formation_model, borehole_model, borehole_geometry_type="diameter", dip=0):
+        if isinstance(formation_model, str):
+            self.formation_model = self.load_formation_parameters(formation_model)
+        elif isinstance(formation_model, np.ndarray):
+            self.formation_model = self.set_formation_parameters(formation_model)
+        if isinstance(borehole_model, str):
+            self.borehole_model = self.load_borehole_parameters(borehole_model, borehole_geometry_type)
+        elif isinstance(borehole_model, np.ndarray):
+            self.borehole_model = self.set_borehole_parameters(borehole_model, borehole_geometry_type)
+        self.dip_deg, self.dip_rad = self.set_dip(dip)
+        self._check_model_geometry()
+
+    @staticmethod
+    def _read_table(path):
+        """Tab-separated table with a name row and a unit row (remo3d.py:395-398, 459-462)."""
+        with open(path) as f:
+            lines = f.read().splitlines()
+        units = lines[1].split()
+        rows = [ln.split("\t") for ln in lines[2:] if ln.strip()]
+        data = np.array([[float(v) for v in r if v.strip() != ""] for r in rows], dtype=float)
+        return np.atleast_2d(data), units
+
+    def load_formation_parameters(self, formation_model_file):
+        data, units = self._read_table(formation_model_file)
+        return self.set_formation_parameters(data, units[:-2])
+
+    def set_formation_parameters(self, formation_parameters, formation_units=["M", "M", "M"]):
+        fp = formation_parameters
+        for i, u in enumerate(formation_units):
+            if u not in CONVERSION:
+                raise ValueError("{} unit in formation model file not recognized. Allowed units: M, DM, CM, MM, IN, FT".format(u))
+            fp[:, i] *= CONVERSION[u]   # in place, like the reference (remo3d.py:427)
+        if (np.diff(fp[:, :2], axis=0) <= 0.0).any() or (fp[1:, 0] != fp[:-1, 1]).any():
+            raise ValueError("Uncorrect formation model geometry")
+        if np.nanmin(fp[:, [3, 4]]) <= 0.0:
+            raise ValueError("Formation resistivies have to be higher than 0 ohmm")
+        return fp
+
+    def load_borehole_parameters(self, borehole_model_file, borehole_geometry_type="diameter"):
+        data, units = self._read_table(borehole_model_file)
+        return self.set_borehole_parameters(data, borehole_geometry_type=borehole_geometry_type, borehole_units=units[:-1])
+
+    def set_borehole_parameters(self, borehole_parameters, borehole_geometry_type="diameter", borehole_units=["M", "M"]):
+        bp = borehole_parameters
+        if np.shape(bp)[0] < 2:
+            raise ValueError("Borehole paramaters have to be defined for at least two depths")
+        for i, u in enumerate(borehole_units):
+            if u not in CONVERSION:
+                raise ValueError("{} unit in borehole model file not recognized. Allowed units: M, DM, CM, MM, IN, FT".format(u))
+            bp[:, i] *= CONVERSION[u]
+        if (np.diff(bp[:, 0], axis=0) <= 0.0).any() or (bp[:, 1] <= 0.0).any():
+            raise ValueError("Uncorrect borehole model geometry")
+        if borehole_geometry_type == "diameter":
+            bp[:, 1] /= 2
+        elif borehole_geometry_type != "radius":
+            raise ValueError("Uncorrect borehole geometry type - use 'diameter' or 'radius' to specify borehole geometry")
+        if np.nanmin(bp[:, 2]) <= 0.0:
+            raise ValueError("Drilling mud resistivies have to be higher than 0 ohmm")
+        return bp
+
+    def set_dip(self, dip):
+        if dip < 0 or dip >= 90:
+            raise ValueError("Uncorrect dip angle")
+        return dip, dip * np.pi / 180
+
+    def _check_model_geometry(self):
+        for i in range(np.shape(self.formation_model)[0]):
+            inside = (self.borehole_model[:, 0] >= self.formation_model[i, 0]) & (self.borehole_model[:, 0] <= self.formation_model[i, 1])
+            if np.any(self.borehole_model[inside, 1] >= self.formation_model[i, 2]):
+                raise ValueError("Borehole radius have to be smaller than the extend of the filtration zone")
+
+    def _add_points_to_borehole(self, maximal_distance=0.15):
+        """Densify the borehole polyline for 3D models (remo3d.py:694-720).  Unlike the reference
+        (Appendix A of SURVEY.md: unbound variable) an already dense model is returned unchanged."""
+        bm = self.borehole_model
+        depths = [bm[0, 0]]
+        for i in range(1, bm.shape[0]):
+            gap = bm[i, 0] - bm[i - 1, 0]
+            if gap > maximal_distance:
+                depths += list(np.linspace(bm[i - 1, 0], bm[i, 0], np.max([3, int(gap * 10 + 1)]))[1:])
+            else:
+                depths.append(bm[i, 0])
+        depths = np.asarray(depths)
+        if depths.shape[0] > bm.shape[0]:
+            return np.vstack([depths, np.interp(depths, bm[:, 0], bm[:, 1]), np.interp(depths, bm[:, 0], bm[:, 2])]).T
+        return bm
+
+    # -- workers (remo3d.py:552-599, 887-899) ------------------------------------------------------
+    def initialize_workers(self, cpu_workers=4, gpu_workers=0):
+        """The reference spawns MPI workers here; this build opens the GPU context of the calling
+        process (device = LOCAL_RANK under torchrun).  The worker counts are validated as in the
+        reference and otherwise only recorded: parallelism across GPUs comes from the launcher."""
+        if type(cpu_workers) != int or type(gpu_workers) != int:
+            raise ValueError("The number of processes have to be an intager")
+        if cpu_workers < 1:
+            raise ValueError("Minimal number of cpu workers is 1")
+        if gpu_workers < 0:
+            raise ValueError("Minimal number of gpu workers is 0")
+        self.cpu_workers, self.gpu_workers = cpu_workers, gpu_workers
+        from . import solver
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.ctx = solver.Context(device)
+
+    def shutdown_workers(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    # -- tasks (remo3d.py:602-692) -----------------------------------------------------------------
+    def _prepare_simulation_depths_and_tasks(self, measurement_depths, batch_size):
+        return tasks.build_batches(self.tools, self.sec, measurement_depths, batch_size)
+
+    # -- the sweep (remo3d.py:723-884 + workers/worker.py:74-142) ----------------------------------
+    def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
+                      condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: float = 1.0, rtol: float = 1e-8,
+                      maxsteps: int = 1000, verbose: bool = True):
+        from . import solver, sweep
+        start = time.time()
+        measurement_depths = np.asarray(measurement_depths, dtype=float)
+        alert = False
+        for t in self.tools.values():
+            far = np.max(np.abs(t[0, :3]))
+            if far > domain_radius:
+                raise ValueError("Some electrodes are locate outside the simulation domain. Domain size have to be increased")
+            alert |= far > 0.75 * domain_radius
+        if alert and verbose:
+            print("Some electrodes are located close to the boundary of the simulation domain. This may cause problems during simulation. "
+                  "Consider increase of the domain size")
+        if mesh_generator not in ("auto", "gmsh", "netgen"):
+            raise ValueError("mesh_generator has to be 'auto', 'gmsh' or 'netgen'")
+        is3d = not np.isclose(self.dip_deg, 0)
+        if is3d and mesh_generator == "netgen":
+            raise ValueError("The only mesh generator supported in 3D models is gmsh")
+        if preconditioner not in ("local", "multigrid"):
+            raise ValueError("preconditioner has to be 'local' or 'multigrid'")
+        if self.ctx is None:
+            raise RuntimeError("initialize_workers() has to be called before simulate_logs()")
+        if self.dip_deg != 0:
+            self.borehole_model = self._add_points_to_borehole()
+        dim = 3 if is3d else 2
+        provider = mesh_provider or default_mesh_provider(scale=mesh_scale)
+
+        simulation_depths, batches = self._prepare_simulation_depths_and_tasks(measurement_depths, batch_size)
+        borehole_geometry = np.ascontiguousarray(self.borehole_model[:, :2])
+        mud = np.interp(simulation_depths, self.borehole_model[:, 0], self.borehole_model[:, 2])
+        if verbose and sweep.rank() == 0:
+            print("{} simulation tasks prepared".format(len(batches)))
+        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps)
+
+        n_tools = len(self.tools)
+        results = np.zeros((len(measurement_depths), n_tools))
+        t_solve = t_mesh = 0.0
+        n_points = 0
+        for bi in sweep.my_share(len(batches)):
+            batch = batches[bi]
+            rows = [(r.depth_index, r.tool_index) for s in batch.solves for r in s.records]
+            try:
+                t0 = time.time()
+                fg, bh, sigma = geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0,
+                                                           mud[bi], simulation_depths[bi], domain_radius)
+                mesh = provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
+                sources, evals, readers = tasks.batch_rhs(batch, self.tools)
+                t1 = time.time()
+                outs, st, rc = self.ctx.solve_batch(mesh, sigma, sources, evals, opts)
+                t2 = time.time()
+                t_mesh += t1 - t0
+                t_solve += t2 - t1
+                for u, rd in zip(outs, readers):
+                    for (di, ti, K, o, m) in rd:
+                        results[di, ti] = tasks.apparent_resistivity(u[o:o + m], m, K, dim)
+                        n_points += 1
+            except Exception:
+                for di, ti in rows:      # any failure in a batch -> NaN for its records (worker.py:135-138)
+                    results[di, ti] = np.nan
+        results = sweep.combine(results)
+        self.logs = {name: np.vstack([measurement_depths, results[:, i]]).T for i, name in enumerate(self.tools.keys())}
+        self.timing = dict(total_s=time.time() - start, mesh_s=t_mesh, solve_s=t_solve, points=n_points, batches=len(batches))
+        if verbose and sweep.rank() == 0:
+            print("\nProcessed in: ", datetime.timedelta(seconds=self.timing["total_s"]))
+
+    # -- results (remo3d.py:902-991; plotting is presentation and out of scope) ---------------------
+    def save_results(self, output_folder=None, measurements_to_save="auto", **plot_options):
+        if output_folder is None:
+            return None
+        sub = os.path.join(output_folder, "Results_{}/".format(datetime.datetime.now().strftime("%Y_%m_%d__%H_%M_%S")))
+        os.makedirs(sub, exist_ok=True)
+        pending = list(self.logs.keys()) if measurements_to_save == "auto" else list(measurements_to_save)
+        n = 1
+        written = []
+        while pending:
+            head = pending[0]
+            group = [head] + [k for k in pending[1:] if self.logs[k].shape[0] == self.logs[head].shape[0]
+                              and np.all(np.isclose(self.logs[head][:, 0], self.logs[k][:, 0]))]
+            pending = [k for k in pending if k not in group]
+            table = np.hstack([self.logs[head]] + [self.logs[k][:, 1:2] for k in group[1:]])
+            header = "\t".join(["DEPTH"] + group) + "\n" + "\t".join(["M"] + ["OHMM"] * len(group))
+            path = sub + "Results_{}.txt".format(n)
+            np.savetxt(path, table, fmt="%.4f", delimiter="\t", header=header, comments="")
+            written.append(path)
+            n += 1
+        return written

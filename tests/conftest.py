@@ -44,3 +44,9 @@ def gpu_ctx():
     ctx = solver.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def examples_dir():
+    """Input / output DATA files of the reference's Examples (CC BY 4.0, README.md:30) kept as fixtures."""
+    return os.path.join(ROOT, "tests", "golden", "examples")

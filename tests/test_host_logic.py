@@ -1,0 +1,128 @@
+"""Host bookkeeping (tool tables, batching, model loading, windowing) against golden vectors
+generated from the reference's own functions (tests/golden/make_golden.py).  Bit-exact for
+indices, 1e-12 for floats."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from remo3d_amd import geometry, tasks, tools
+from remo3d_amd.model import Model
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def test_tool_tables_match_reference():
+    gold = load("tools.json")
+    for key, case in gold.items():
+        if key == "rejects":
+            continue
+        tables, sec = tools.tool_tables(case["names"], case["force"])
+        assert sec == case["sec"], key
+        assert list(tables.keys()) == case["names"]
+        for name in case["names"]:
+            np.testing.assert_allclose(tables[name], np.array(case["tables"][name]), rtol=1e-13, atol=1e-13, err_msg=f"{key} {name}")
+    # a known value from SURVEY.md section 8c
+    t, _ = tools.tool_tables(["A2.0M0.5N"])
+    np.testing.assert_allclose(t["A2.0M0.5N"], [[0, 2, 2.5, 125.66370614359172], [1, 0, 0, -2.25]], rtol=1e-12)
+
+
+def test_bad_tool_names_rejected_like_reference():
+    for name, rejected in load("tools.json")["rejects"]:
+        if rejected is True:
+            with pytest.raises(ValueError):
+                tools.tool_tables([name])
+    with pytest.raises(ValueError):
+        tools.tool_tables("A2.0M0.5N")          # not a list
+    with pytest.raises(ValueError):
+        tools.tool_tables(["A2.0M0.5N"], 1)     # flag not a bool
+
+
+@pytest.mark.parametrize("fixture", ["tasks_example_01.json", "tasks_bm3.json", "tasks_bm1_single.json", "tasks_nonsec.json",
+                                     "tasks_example_02.json"])
+def test_batching_matches_reference(fixture):
+    gold = load(fixture)
+    tables, sec = tools.tool_tables(gold["names"], gold["force"])
+    assert sec == gold["sec"]
+    combined, batches = tasks.build_batches(tables, sec, np.array(gold["depths"]), gold["batch_size"])
+    np.testing.assert_allclose(combined, gold["simulation_depths"], rtol=0, atol=1e-12)
+    mine = tasks.to_reference_layout(batches)
+    ref = gold["tasks"]
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):
+        assert a[0] == b[0]
+        np.testing.assert_allclose(np.array(a[1]), np.array(b[1]), rtol=0, atol=1e-12)
+        assert len(a[2]) == len(b[2])
+        for sa, sb in zip(a[2], b[2]):
+            assert sa[0] == sb[0]
+            np.testing.assert_allclose(np.array(sa[1]), np.array(sb[1]), rtol=0, atol=1e-12)
+            assert len(sa[2]) == len(sb[2])
+            for ra, rb in zip(sa[2], sb[2]):
+                assert ra[0] == rb[0] and ra[1] == rb[1]
+                assert abs(ra[2] - rb[2]) < 1e-12
+
+
+def test_survey_counts():
+    """Example_01 -> 164 batches / 818 solves / 1506 records; BM3 -> 40 / 200."""
+    g = load("tasks_example_01.json")
+    tables, sec = tools.tool_tables(g["names"], True)
+    _, b = tasks.build_batches(tables, sec, np.array(g["depths"]), 5)
+    assert len(b) == 164 and sum(len(x.solves) for x in b) == 818
+    assert sum(len(s.records) for x in b for s in x.solves) == 1506
+    g = load("tasks_bm3.json")
+    tables, sec = tools.tool_tables(g["names"], True)
+    _, b = tasks.build_batches(tables, sec, np.array(g["depths"]), 5)
+    assert len(b) == 40 and sum(len(x.solves) for x in b) == 200
+
+
+@pytest.mark.parametrize("fixture", ["windows_example_01.json", "windows_example_01_r5.json", "windows_bm2.json", "windows_bm2_r8.json",
+                                     "windows_bm3_30.json", "windows_bm3_60_r6.json"])
+def test_model_loading_and_windowing_match_reference(fixture, examples_dir):
+    gold = load(fixture)
+    m = Model(["A0.4M6.0N", "A2.0M0.5N"])
+    m.set_model_parameters(os.path.join(examples_dir, gold["formation_file"]), os.path.join(examples_dir, gold["borehole_file"]),
+                           dip=gold["dip_deg"])
+    np.testing.assert_allclose(m.formation_model, np.array(gold["formation_model"], dtype=float), rtol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(m.borehole_model, np.array(gold["borehole_model_loaded"]), rtol=1e-14)
+    if m.dip_deg != 0:
+        m.borehole_model = m._add_points_to_borehole()
+    np.testing.assert_allclose(m.borehole_model, np.array(gold["borehole_model"]), rtol=1e-13)
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    for case in gold["cases"]:
+        fg, bh, sigma = geometry.select_data_range(bg, m.formation_model, m.dip_rad, case["rm"], case["depth"], gold["R"])
+        np.testing.assert_allclose(fg, np.array(case["formation_geometry"], dtype=float), rtol=1e-13, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(bh, np.array(case["borehole_geometry"]), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(sigma, case["sigma"], rtol=1e-13)
+
+
+def test_batch_rhs_and_ra_formula():
+    tables, sec = tools.tool_tables(["A0.4M6.0N", "A2.0M0.5N"])
+    _, batches = tasks.build_batches(tables, sec, np.linspace(5, 20, 100, endpoint=False), 5)
+    src, ev, readers = tasks.batch_rhs(batches[3], tables)
+    assert len(src) == len(batches[3].solves) == len(ev)
+    for (z, I), s in zip(src, batches[3].solves):
+        assert np.all(I == 1.0) and len(z) >= 1      # single-electrode mode: unit sources (remo3d.py:288-295, 659-660)
+    # homogeneous full space: u = 1/(4 pi sigma r)  =>  Ra = 1/sigma exactly (remo3d.py:285-306)
+    sigma = 0.25
+    for name, t in tables.items():
+        meas = t[0, :3][t[1, :3] == 0]
+        cur = t[0, :3][t[1, :3] != 0][0]
+        u = 1.0 / (4 * np.pi * sigma * np.abs(meas - cur))
+        assert abs(tasks.apparent_resistivity(u, 2, t[0, 3], 2) - 1 / sigma) < 1e-12
+        assert abs(tasks.apparent_resistivity(2 * u, 2, t[0, 3], 3) - 1 / sigma) < 1e-12   # half-space model, halved (worker.py:129)
+
+
+def test_results_writer_layout(tmp_path):
+    m = Model(["A0.4M6.0N", "A2.0M0.5N"])
+    d = np.array([1.0, 1.1, 1.2])
+    m.logs = {"A0.4M6.0N": np.vstack([d, [5.0, 5.1234567, 6.0]]).T, "A2.0M0.5N": np.vstack([d, [7.0, 8.0, np.nan]]).T}
+    files = m.save_results(str(tmp_path))
+    lines = open(files[0]).read().splitlines()
+    assert lines[0] == "DEPTH\tA0.4M6.0N\tA2.0M0.5N" and lines[1] == "M\tOHMM\tOHMM"
+    assert lines[3] == "1.1000\t5.1235\t8.0000" and lines[4].endswith("nan")

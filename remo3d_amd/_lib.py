@@ -46,7 +46,7 @@ class RemoStats(C.Structure):
 
 EXPORTS = ["remo_abi_version", "remo_opts_default", "remo_ctx_create", "remo_ctx_destroy", "remo_last_error",
            "remo_solve_batch", "remo_batch_create", "remo_batch_run", "remo_batch_fetch", "remo_batch_destroy",
-           "remo_batch_get_system", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_symbolic"]
+           "remo_batch_get_system", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_symbolic", "remo_debug_tune"]
 
 _lib = None
 
@@ -87,6 +87,7 @@ def load():
     L.remo_host_element_matrix.argtypes = [C.c_int32, dp, C.c_double, dp]
     L.remo_host_symbolic.restype = C.c_int
     L.remo_host_symbolic.argtypes = [C.POINTER(RemoMesh), C.c_int32, i64p, ip, ip, ip]
+    L.remo_debug_tune.argtypes = [C.c_int32, C.c_int32]
     _lib = L
     return L
 

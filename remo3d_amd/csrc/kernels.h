@@ -6,7 +6,7 @@
 
 namespace remo {
 
-constexpr int kMaxPartialBlocks = 1024;  // grid cap of every kernel that leaves per-block partial sums
+constexpr int kMaxPartialBlocks = 1024;   // grid cap of every kernel that leaves per-block partial sums
 constexpr int kMaxPoints = 256;          // sources + evaluation points of one RHS chunk
 
 // per-iteration record the PCG kernels write straight into mapped host memory
@@ -19,8 +19,8 @@ struct PcgProgress {
 struct PcgBuffers {
     double *x, *r, *p, *q;  // [n*k]
     const double *dinv;     // [n]
-    double *part_pq;        // [kMaxPartialBlocks*8]
-    double *part_rz;        // [2][kMaxPartialBlocks*8]
+    double *part_pq;        // [kMaxPartialBlocks*8] per-workgroup partial sums of <p, Ap>
+    double *part_rz;        // [2][kMaxPartialBlocks*8] per-workgroup partial sums of <Cr, r> (even / odd step)
     double *rz0;            // [8] device copy of <Cr0,r0>
     PcgProgress *progress;  // mapped host ring [progress_len]
     int progress_len;
@@ -42,8 +42,10 @@ void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowpt
                      const double *M, double *val, double *dinv, hipStream_t s);
 
 int spmv_grid(int64_t n, int lanes_per_row);
+int vec_grid(int64_t n);
+void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 threads, 3 mapping, 4 grid (0 = default)
 int choose_lanes_per_row(int64_t n, int64_t nnz);
-// y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of x.y
+// y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
 void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nblocks, hipStream_t s);
 
 void launch_pcg_init(int64_t n, int k, const double *f, const PcgBuffers &b, hipStream_t s);

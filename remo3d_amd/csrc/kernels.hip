@@ -59,6 +59,13 @@ template <int K> __device__ __forceinline__ void reduce_partials(const double *p
     for (int c = 0; c < K; ++c) out[c] = v[c];
 }
 
+template <int K> __device__ __forceinline__ double pick(const double (&a)[K], int c) {
+    double r = a[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) r = (c == j) ? a[j] : r;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // metric terms: one thread per element (ngsolve_functions.py:33-36: the coefficient part of the
 // integrand; sigma per material as worker.py:101)
@@ -174,17 +181,71 @@ void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowpt
 // LPR partial sums are combined with wave shuffles.  Optionally leaves per-block partial sums of
 // <x, y> (the CG's <p, Ap>) so the dot product costs no extra pass.
 
+// first row r in [0, n] with rowptr[r] >= target
+__device__ __forceinline__ int64_t row_of_offset(const int32_t *__restrict__ rowptr, int64_t n, int64_t target) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct d2 { double a, b; };
+// 16 bytes from an 8-byte-aligned address: one global_load_dwordx4 (gfx950 runs in unaligned-access mode)
+__device__ __forceinline__ d2 load16(const double *p) {
+    d2 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// Row walk shared by the SpMM variants.  mapping 0: plain grid-stride over row groups.
+// mapping 1 (XCD-aware, speed only): workgroups b and b + 8 share an XCD and its 4 MiB L2, so
+// each residue class mod 8 walks one contiguous, nnz-balanced row range and the x rows it gathers
+// stay within one slice of each entity block.
+struct RowWalk {
+    int64_t begin, end, step;
+};
+__device__ __forceinline__ RowWalk row_walk(int mapping, int64_t n, int64_t nnz, const int32_t *__restrict__ rowptr, int rpb, int grp) {
+    RowWalk w;
+    if (mapping == 0) {
+        w.begin = int64_t(blockIdx.x) * rpb + grp;
+        w.end = n;
+        w.step = int64_t(gridDim.x) * rpb;
+    } else if (mapping == 1) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+        const int64_t r0 = row_of_offset(rowptr, n, (nnz * xcd) >> 3);
+        w.end = (xcd == 7) ? n : row_of_offset(rowptr, n, (nnz * (xcd + 1)) >> 3);
+        w.begin = r0 + int64_t(slot) * rpb + grp;
+        w.step = int64_t(per_xcd) * rpb;
+    } else {
+        // mapping 2/3: every workgroup walks ONE contiguous, nnz-balanced row range front to back, so
+        // the x rows gathered by consecutive passes overlap and stay in the CU's L1; with mapping 3
+        // the ranges of one XCD (workgroups b, b + 8, ...) are also adjacent to each other.
+        const int nb = gridDim.x;
+        const int chunk = (mapping == 3) ? ((blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
+        const int64_t r0 = row_of_offset(rowptr, n, (nnz * chunk) / nb);
+        w.end = (chunk == nb - 1) ? n : row_of_offset(rowptr, n, (nnz * (chunk + 1)) / nb);
+        w.begin = r0 + grp;
+        w.step = rpb;
+    }
+    return w;
+}
+
+// Variant A ("lane per nonzero"): every lane owns one stored entry and all K columns of it; the x
+// row is gathered with K 8-byte loads.
 template <int K, int LPR, bool DOT>
-__global__ void __launch_bounds__(256) k_spmm(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                              const double *__restrict__ val, const double *__restrict__ x,
-                                              double *__restrict__ y, double *__restrict__ part) {
-    constexpr int RPB = 256 / LPR;  // rows per block pass
+__global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
+                                              const int32_t *__restrict__ col, const double *__restrict__ val,
+                                              const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+    const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
+    const RowWalk w = row_walk(mapping, n, nnz, rowptr, rpb, grp);
     double dot[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) dot[c] = 0.0;
-    for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < n; row += int64_t(gridDim.x) * RPB) {
+    for (int64_t row = w.begin; row < w.end; row += w.step) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
         double acc[K];
 #pragma unroll
@@ -210,35 +271,161 @@ __global__ void __launch_bounds__(256) k_spmm(int64_t n, const int32_t *__restri
     if (DOT) {
         __shared__ double smem[16 * K];
         block_sum<K>(dot, smem);
-        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = dot[threadIdx.x];
+        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
+    }
+}
+
+// Variant B ("chunk lanes"): a fully divergent gather costs the texture-address path one cache
+// line visit per lane and instruction, so K 8-byte loads per stored entry visit ~5 K lines per 64
+// entries.  Here LQ = 1/2/4 adjacent lanes share one stored entry and each loads ONE 16-byte chunk
+// (two columns) of its x row: one instruction serves 64/LQ entries and all their columns, adjacent
+// lanes hit the same line, and every lane carries two accumulators instead of K.  The K interleaved
+// right-hand sides stay compact ([n][K], 8-byte aligned rows); for odd K the last chunk's second
+// half is the next row's first value (read, never used; buffers carry 16 bytes of slack).
+template <int K> struct Chunks {
+    static constexpr int CH = (K + 1) / 2;                       // 16-byte chunks per x row
+    static constexpr int LQ = (CH <= 1) ? 1 : ((CH <= 2) ? 2 : 4);  // lanes per stored entry
+};
+
+template <int K, int LPR, bool DOT>
+__global__ void __launch_bounds__(512) k_spmm_chunk(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+    constexpr int CH = Chunks<K>::CH, LQ = Chunks<K>::LQ, NZ = LPR / LQ;  // NZ entries per row pass
+    static_assert(LPR >= LQ && LPR <= 64, "lanes per row");
+    const int rpb = blockDim.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int q = sub % LQ;       // which chunk of the x row
+    const int slot = sub / LQ;    // which entry of the pass
+    const bool active = q < CH;
+    const bool second = (2 * q + 1) < K;
+    const RowWalk w = row_walk(mapping, n, nnz, rowptr, rpb, grp);
+    double dot0 = 0.0, dot1 = 0.0;
+    for (int64_t row = w.begin; row < w.end; row += w.step) {
+        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        double acc0 = 0.0, acc1 = 0.0;
+        int32_t p = rs + slot;
+        for (; p + NZ < re; p += 2 * NZ) {  // two entries in flight per lane
+            const double v0 = val[p], v1 = val[p + NZ];
+            const int64_t j0 = col[p], j1 = col[p + NZ];
+            if (active) {
+                const d2 a = load16(x + j0 * K + 2 * q);
+                const d2 b = load16(x + j1 * K + 2 * q);
+                acc0 += v0 * a.a; acc1 += v0 * a.b;
+                acc0 += v1 * b.a; acc1 += v1 * b.b;
+            }
+        }
+        if (p < re) {
+            const double v0 = val[p];
+            const int64_t j0 = col[p];
+            if (active) {
+                const d2 a = load16(x + j0 * K + 2 * q);
+                acc0 += v0 * a.a; acc1 += v0 * a.b;
+            }
+        }
+#pragma unroll
+        for (int off = LQ; off < LPR; off <<= 1) {
+            acc0 += __shfl_xor(acc0, off, 64);
+            acc1 += __shfl_xor(acc1, off, 64);
+        }
+        if (slot == 0 && active) {
+            y[row * K + 2 * q] = acc0;
+            if (second) y[row * K + 2 * q + 1] = acc1;
+            if (DOT) {
+                const d2 xr = load16(x + row * K + 2 * q);
+                dot0 += acc0 * xr.a;
+                if (second) dot1 += acc1 * xr.b;
+            }
+        }
+    }
+    if (DOT) {
+        // lanes with equal q hold partial sums of columns (2q, 2q+1): fold the wave over the
+        // other lane bits, then the waves of the block through LDS (fixed order: deterministic)
+        __shared__ double smem[16 * 2 * LQ];
+#pragma unroll
+        for (int off = LQ; off < 64; off <<= 1) {
+            dot0 += __shfl_xor(dot0, off, 64);
+            dot1 += __shfl_xor(dot1, off, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if (lane < LQ) {
+            smem[(wave * LQ + lane) * 2] = dot0;
+            smem[(wave * LQ + lane) * 2 + 1] = dot1;
+        }
+        __syncthreads();
+        if (threadIdx.x < K) {
+            const int c = threadIdx.x;
+            double sum = 0.0;
+            for (int wv = 0; wv < nw; ++wv) sum += smem[(wv * LQ + (c >> 1)) * 2 + (c & 1)];
+            part[blockIdx.x * K + c] = sum;
+        }
+    }
+}
+
+// tuning knobs (remo_debug_tune): 0 = heuristic default
+struct SpmmTuning {
+    int variant = 0;  // 1 = lane per nonzero, 2 = chunk lanes
+    int lpr = 0;
+    int threads = 0;
+    int mapping = -1;
+    int grid = 0;
+};
+static SpmmTuning g_tune;
+void set_spmm_tuning(int key, int value) {
+    switch (key) {
+        case 0: g_tune.variant = value; break;
+        case 1: g_tune.lpr = value; break;
+        case 2: g_tune.threads = value; break;
+        case 3: g_tune.mapping = value; break;
+        case 4: g_tune.grid = value; break;
+        default: break;
     }
 }
 
 int choose_lanes_per_row(int64_t n, int64_t nnz) {
+    if (g_tune.lpr) return g_tune.lpr;
     const double avg = double(nnz) / double(n > 0 ? n : 1);
     if (avg > 40) return 16;
     if (avg > 20) return 8;
     return 4;
 }
+static int spmm_threads() { return g_tune.threads ? g_tune.threads : 256; }
 
 int spmv_grid(int64_t n, int lpr) {
-    const int64_t rpb = 256 / lpr;
+    if (g_tune.grid) return g_tune.grid;
+    const int64_t rpb = spmm_threads() / lpr;
     int64_t g = (n + rpb - 1) / rpb;
+    g = (g + 7) / 8 * 8;  // whole residue classes mod 8 (one per XCD)
     if (g > kMaxPartialBlocks) g = kMaxPartialBlocks;
-    if (g < 1) g = 1;
+    if (g < 8) g = 8;
     return int(g);
 }
 
 template <int K> static void spmm_dispatch(const CsrView &A, const double *x, double *y, double *part, int nb, hipStream_t s) {
-    const int lpr = choose_lanes_per_row(A.n, A.nnz);
-#define REMO_SPMM(L)                                                                                                  \
-    if (part)                                                                                                         \
-        hipLaunchKernelGGL((k_spmm<K, L, true>), dim3(nb), dim3(256), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part); \
-    else                                                                                                              \
-        hipLaunchKernelGGL((k_spmm<K, L, false>), dim3(nb), dim3(256), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part)
-    if (lpr == 16) { REMO_SPMM(16); }
-    else if (lpr == 8) { REMO_SPMM(8); }
-    else { REMO_SPMM(4); }
+    int lpr = choose_lanes_per_row(A.n, A.nnz);
+    const int threads = spmm_threads();
+    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 0;
+    const int variant = g_tune.variant ? g_tune.variant : 1;
+    constexpr int LQ = Chunks<K>::LQ;
+#define REMO_SPMM(KERNEL, L)                                                                                                          \
+    if (part)                                                                                                                         \
+        hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part); \
+    else                                                                                                                              \
+        hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part)
+    if (variant == 1) {
+        if (lpr >= 32) { REMO_SPMM(k_spmm, 32); }
+        else if (lpr == 16) { REMO_SPMM(k_spmm, 16); }
+        else if (lpr == 8) { REMO_SPMM(k_spmm, 8); }
+        else { REMO_SPMM(k_spmm, 4); }
+    } else {
+        if (lpr < LQ) lpr = LQ;
+        if (lpr >= 64) { REMO_SPMM(k_spmm_chunk, 64); }
+        else if (lpr == 32) { REMO_SPMM(k_spmm_chunk, 32); }
+        else if (lpr == 16) { REMO_SPMM(k_spmm_chunk, 16); }
+        else if (lpr == 8) { REMO_SPMM(k_spmm_chunk, 8); }
+        else { REMO_SPMM(k_spmm_chunk, 4); }
+    }
 #undef REMO_SPMM
 }
 
@@ -299,6 +486,22 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     const double *__restrict__ dinv) {
     __shared__ double smem[16 * K];
     double pq[K], rz[K], alpha[K], acc[K];
+    // issue this thread's first rows BEFORE the scalar reduction: the step length does not affect
+    // the addresses, so the vector loads fly while the workgroup re-reduces the partial sums
+    constexpr int PF = 2;
+    const int64_t gtid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+    double pv[PF][K], qv[PF][K], xv[PF][K], rv[PF][K], dv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int64_t i = gtid + u * nthreads;
+        if (i < n) {
+            dv[u] = dinv[i];
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                pv[u][c] = p[i * K + c]; qv[u][c] = q[i * K + c]; xv[u][c] = x[i * K + c]; rv[u][c] = r[i * K + c];
+            }
+        }
+    }
     reduce_partials<K>(part_pq, nb_spmv, pq, smem);
     __syncthreads();
     reduce_partials<K>(part_rz_cur, nb_vec, rz, smem);
@@ -319,7 +522,22 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int64_t i = gtid + u * nthreads;
+        if (i < n) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const double a = alpha[c];
+                const double xi = xv[u][c] + a * pv[u][c];
+                const double ri = rv[u][c] - a * qv[u][c];
+                x[i * K + c] = xi;
+                r[i * K + c] = ri;
+                acc[c] += ri * ri * dv[u];
+            }
+        }
+    }
+    for (int64_t i = gtid + PF * nthreads; i < n; i += nthreads) {
         const double d = dinv[i];
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -344,6 +562,18 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, double tol2, i
                                                        const double *__restrict__ dinv) {
     __shared__ double smem[16 * K];
     double pq[K], rzo[K], rzn[K], beta[K];
+    constexpr int PF = 2;  // rows in flight per thread while the partial sums are re-reduced
+    const int64_t gtid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
+    double pv[PF][K], rv[PF][K], dv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int64_t i = gtid + u * nthreads;
+        if (i < n) {
+            dv[u] = dinv[i];
+#pragma unroll
+            for (int c = 0; c < K; ++c) { pv[u][c] = p[i * K + c]; rv[u][c] = r[i * K + c]; }
+        }
+    }
     reduce_partials<K>(part_pq, nb_spmv, pq, smem);
     __syncthreads();
     reduce_partials<K>(part_rz_old, nb_vec, rzo, smem);
@@ -354,7 +584,14 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, double tol2, i
         const bool live = (rzo[c] > tol2 * rz0[c]) && (pq[c] > 0.0);
         beta[c] = live ? rzn[c] / rzo[c] : 0.0;
     }
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int64_t i = gtid + u * nthreads;
+        if (i < n)
+#pragma unroll
+            for (int c = 0; c < K; ++c) p[i * K + c] = dv[u] * rv[u][c] + beta[c] * pv[u][c];
+    }
+    for (int64_t i = gtid + PF * nthreads; i < n; i += nthreads) {
         const double d = dinv[i];
 #pragma unroll
         for (int c = 0; c < K; ++c) p[i * K + c] = d * r[i * K + c] + beta[c] * p[i * K + c];
@@ -375,7 +612,7 @@ __global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_vec, const d
     }
 }
 
-static int vec_grid(int64_t n) {
+int vec_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
     if (g < 1) g = 1;

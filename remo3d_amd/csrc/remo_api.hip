@@ -450,11 +450,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // ---- solve, chunk by chunk --------------------------------------------------------
         const int lpr = choose_lanes_per_row(n, sy.nnz);
         buf.nb_spmv = spmv_grid(n, lpr);
-        {
-            int64_t g = (n + 255) / 256;
-            if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
-            buf.nb_vec = int(g < 1 ? 1 : g);
-        }
+        buf.nb_vec = vec_grid(n);
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
         size_t ev_used = 0;
@@ -565,7 +561,7 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     try {
         HIP_TRY(hipSetDevice(ctx->device));
         const int64_t n = b->A.n;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * n * k));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * (n * k + 2)));  // 16 bytes of slack for chunk loads
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dy), sizeof(double) * n * k));
         HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n * k, hipMemcpyHostToDevice));
         const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
@@ -586,6 +582,8 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
 }
+
+void remo_debug_tune(int32_t key, int32_t value) { set_spmm_tuning(key, value); }
 
 int remo_host_element_matrix(int32_t dim, const double *X, double sigma, double *K_out) {
     if ((dim != 2 && dim != 3) || !X || !K_out) return REMO_ERR_ARG;

@@ -155,7 +155,8 @@ def _boundary_facets(conn: np.ndarray):
 def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), scale: float = 1.0,
               material_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None, seed: int = 0,
               h_axis: float = 0.1, h_src: float = 0.01, max_level: int = 18,
-              snap_z: Sequence[float] = (), h_max: Optional[float] = None, jitter: float = 0.12) -> Mesh:
+              snap_z: Sequence[float] = (), h_max: Optional[float] = None, jitter: float = 0.12,
+              improve_passes: int = 6) -> Mesh:
     """Graded Delaunay mesh of the reference's half disc (dim=2) or half ball (dim=3).
 
     sources_z : axis positions of current electrodes (refinement centres, snapped to vertices)
@@ -164,6 +165,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     snap_z    : further axis positions to snap onto vertices (e.g. measuring electrodes)
     h_max     : cap on the size field (default R/5; keeps the polyhedral outer boundary round)
     jitter    : seeded displacement of interior lattice points, fraction of the local cell size
+    improve_passes : sliver-removal passes (3D): perturb vertices of elements with quality < 0.15, re-triangulate
     """
     from scipy.spatial import Delaunay, cKDTree
 
@@ -217,29 +219,52 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
         k = ax_idx[np.argmin(np.abs(pts[ax_idx, zc] - zs))]
         pts[k, zc] = zs
 
-    # Qhull is ~10x slower on exactly coplanar hull points (symmetry plane / axis): triangulate a
-    # copy lifted off the plane by ~1e-9 R, then use the exact coordinates; the flat hull elements
-    # this creates have exactly zero measure afterwards and are removed below.
-    lifted = pts.copy()
-    lift_mask = on_plane.copy()
-    lifted[lift_mask, 0 if dim == 2 else 1] += (0.5 + rng.random(int(lift_mask.sum()))) * 1e-9 * R
-    tri = Delaunay(lifted)
-    conn = tri.simplices.astype(np.int64)
-    # drop flat elements (coplanar hull points) and elements with every vertex on the sphere
-    P = pts[conn]
-    if dim == 2:
-        a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]
-        vol = 0.5 * np.abs(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
-    else:
-        a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]; c = P[:, 3] - P[:, 0]
-        vol = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c))) / 6.0
-    emax = np.zeros(len(conn))
-    for i in range(dim + 1):
-        for j in range(i + 1, dim + 1):
-            emax = np.maximum(emax, np.sqrt(((P[:, i] - P[:, j]) ** 2).sum(1)))
     on_sph = np.sqrt((pts ** 2).sum(1)) >= R * (1 - 1e-12)
-    ok = (vol > 1e-9 * emax ** dim) & (~np.all(on_sph[conn], axis=1))
-    conn = conn[ok]; vol = vol[ok]
+
+    def triangulate(pts):
+        # Qhull is ~10x slower on exactly coplanar hull points (symmetry plane / axis): triangulate
+        # a copy lifted off the plane by ~1e-9 R, then use the exact coordinates; the flat hull
+        # elements this creates have exactly zero measure afterwards and are removed.
+        lifted = pts.copy()
+        lifted[on_plane, 0 if dim == 2 else 1] += (0.5 + rng.random(int(on_plane.sum()))) * 1e-9 * R
+        conn = Delaunay(lifted).simplices.astype(np.int64)
+        P = pts[conn]
+        if dim == 2:
+            a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]
+            vol = 0.5 * np.abs(a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
+        else:
+            a = P[:, 1] - P[:, 0]; b = P[:, 2] - P[:, 0]; c = P[:, 3] - P[:, 0]
+            vol = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c))) / 6.0
+        edges = np.stack([np.sqrt(((P[:, i] - P[:, j]) ** 2).sum(1)) for i in range(dim + 1) for j in range(i + 1, dim + 1)], 1)
+        # drop flat elements (coplanar hull points) and elements with every vertex on the sphere
+        ok = (vol > 1e-9 * edges.max(1) ** dim) & (~np.all(on_sph[conn], axis=1))
+        conn, vol, edges = conn[ok], vol[ok], edges[ok]
+        rms = np.sqrt((edges ** 2).mean(1))
+        qual = vol / rms ** dim * (4 / np.sqrt(3) if dim == 2 else 6 * np.sqrt(2))   # 1 for the regular simplex
+        return conn, vol, edges, qual
+
+    conn, vol, edges, qual = triangulate(pts)
+    # Sliver removal.  A plain Delaunay tetrahedralisation keeps a few almost flat elements
+    # ("slivers"); production meshers (Gmsh's optimiser, which the reference relies on) remove them,
+    # and they cost the Jacobi-PCG ~1.5x in steps.  Perturb the movable vertices of poor elements by a
+    # fraction of their shortest edge and re-triangulate, a few passes (seeded, deterministic).
+    pinned = on_sph | on_axis
+    for zs in list(sources_z) + list(snap_z):
+        if ax_idx.size:
+            pinned[ax_idx[np.argmin(np.abs(pts[ax_idx, zc] - zs))]] = True
+    for _ in range(improve_passes if dim == 3 else 0):
+        bad = qual < 0.15
+        if not bad.any():
+            break
+        vb = conn[bad]; hb = edges[bad].min(1)
+        for k in range(dim + 1):
+            v = vb[:, k]
+            mv = ~pinned[v]
+            step = (rng.random((int(mv.sum()), dim)) - 0.5) * 0.5 * hb[mv][:, None]
+            step[on_plane[v[mv]], 1] = 0.0     # symmetry-plane vertices move in their plane
+            pts[v[mv]] += step
+        conn, vol, edges, qual = triangulate(pts)
+    emax = edges.max(1)
 
     # remove unused points, renumber along a Morton-like order for locality (sort by tree cell)
     used = np.zeros(len(pts), bool); used[conn.ravel()] = True
@@ -260,7 +285,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     mat = np.zeros(len(conn), dtype=np.int32) if material_fn is None else np.asarray(material_fn(cent), dtype=np.int32)
     exact = (np.pi * R * R / 2) if dim == 2 else (2.0 / 3.0 * np.pi * R ** 3)
     meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z],
-                volume=float(vol.sum()), volume_exact=float(exact))
+                volume=float(vol.sum()), volume_exact=float(exact), min_quality=float(qual.min()))
     return Mesh(dim, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)),
                 np.ascontiguousarray(mat), np.ascontiguousarray(bf.astype(np.int32)),
                 np.ascontiguousarray(bdir.astype(np.uint8)), meta)

@@ -122,6 +122,15 @@ int remo_batch_fetch(remo_ctx_t *ctx, remo_batch_t *batch, double *u_out);
 void remo_batch_destroy(remo_ctx_t *ctx, remo_batch_t *batch);
 
 /*
+ * u_h of right-hand side `rhs` of the last remo_batch_run at further axis points - the
+ * `gfu(mesh(0.0, z))` / `gfu(mesh(0.0, 0.0, z))` of worker.py:124-131 for callers that keep the
+ * solution object around (remo3d_amd/ngsolve_functions_hip.py).  Valid until the next run on the
+ * context, for batches of at most REMO_MAX_RHS right-hand sides.  Points outside the mesh give
+ * NaN and REMO_ERR_POINT.
+ */
+int remo_batch_eval(remo_ctx_t *ctx, remo_batch_t *batch, int32_t rhs, int32_t n_points, const double *z, double *u_out);
+
+/*
  * Inspection hooks used by the parity tests (tests/): the assembled system of the last
  * remo_batch_run on this batch.  Pass NULL to skip an array.  rowptr[n_free+1], col[nnz],
  * val[nnz], dinv[n_free] (Jacobi), freeid[n_dof] (free row of each dof or -1).

@@ -60,6 +60,7 @@ struct remo_ctx {
     int32_t *d_err = nullptr;
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> spmv_ev;
+    uint64_t run_id = 0;  // the arena holds the system / solution of the batch that ran last
 
     template <class T> T *take(size_t count) { return ar.lo<T>(count); }
     void reserve(size_t bytes) {
@@ -102,6 +103,9 @@ struct remo_batch {
     DeviceSymbolic sym;
     CsrView A{};
     double *d_val = nullptr, *d_dinv = nullptr;
+    double *d_x = nullptr, *d_C = nullptr;  // solution block [n][k_last] and metric terms of the last run
+    int k_last = 0;
+    uint64_t run_id = 0;
     std::vector<double> u_out;
 };
 
@@ -343,6 +347,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
     std::memset(st, 0, sizeof *st);
     std::fill(b->u_out.begin(), b->u_out.end(), std::nan(""));
     b->has_system = false;
+    b->run_id = ++ctx->run_id;
     const double t_start = now_ms();
     try {
         HIP_TRY(hipSetDevice(ctx->device));
@@ -445,6 +450,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->d_val = d_val;
         b->d_dinv = d_dinv;
+        b->d_x = buf.x;
+        b->d_C = d_C;
+        b->k_last = 0;
         b->has_system = true;
 
         // ---- solve, chunk by chunk --------------------------------------------------------
@@ -480,6 +488,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             ms_eval += e1 + e3;
             ms_solve += e2;
             if (!cr.finite) return fail(ctx, REMO_ERR_NUMERIC, "non-finite residual in PCG");
+            b->k_last = k;
             if (!cr.converged) ret = REMO_NOT_CONVERGED;
             for (int c = 0; c < k; ++c) {
                 st->iterations[c] = cr.iters[c];
@@ -536,10 +545,51 @@ int remo_solve_batch(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, co
     return rc;
 }
 
+int remo_batch_eval(remo_ctx_t *ctx, remo_batch_t *b, int32_t rhs, int32_t npts, const double *z, double *u_out) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || !z || !u_out || npts <= 0) return fail(ctx, REMO_ERR_ARG, "bad argument");
+    for (int i = 0; i < npts; ++i) u_out[i] = std::nan("");
+    if (!b->has_system || b->run_id != ctx->run_id || b->k_last <= 0 || b->n_rhs > REMO_MAX_RHS)
+        return fail(ctx, REMO_ERR_ARG, "no resident solution for this batch (another batch ran on the context since)");
+    if (rhs < 0 || rhs >= b->k_last) return fail(ctx, REMO_ERR_ARG, "rhs index out of range");
+    void *scratch = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const DeviceSymbolic &sy = b->sym;
+        const int dim = b->dim, N = (dim == 2) ? 10 : 20;
+        const size_t bytes = size_t(npts) * (sizeof(double) * (4 + N) + sizeof(int32_t) * 2) + 1024;
+        HIP_TRY(hipMalloc(&scratch, bytes));
+        double *d_z = static_cast<double *>(scratch), *d_I = d_z + npts, *d_phi = d_I + npts, *d_fint = d_phi + size_t(npts) * N, *d_out = d_fint + npts;
+        int32_t *d_rhs = reinterpret_cast<int32_t *>(d_out + npts), *d_found = d_rhs + npts;
+        std::vector<int32_t> h_rhs(npts, rhs), h_found(npts, INT_MAX);
+        HIP_TRY(hipMemsetAsync(scratch, 0, bytes, s));   // strengths 0 (evaluation points), no bubble loads
+        HIP_TRY(hipMemsetAsync(ctx->d_err, 0, sizeof(int32_t), s));
+        HIP_TRY(hipMemcpyAsync(d_z, z, sizeof(double) * npts, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_rhs, h_rhs.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_found, h_found.data(), sizeof(int32_t) * npts, hipMemcpyHostToDevice, s));
+        for (int q0 = 0; q0 < npts; q0 += kMaxPoints)
+            launch_locate(dim, b->nt, b->d_coords, sy.conn, std::min(kMaxPoints, npts - q0), d_z + q0, d_found + q0, s);
+        launch_point_shapes(dim, npts, d_z, d_found, b->d_coords, sy.conn, d_phi, ctx->d_err, s);
+        const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
+        launch_eval(dim, sy.condense, npts, d_rhs, d_I, d_found, d_phi, sy.eldof, b->d_C, d_M, b->k_last, b->d_x, d_fint, d_out, s);
+        int32_t h_err = 0;
+        HIP_TRY(hipMemcpyAsync(u_out, d_out, sizeof(double) * npts, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(scratch);
+        if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "evaluation point outside the mesh");
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (scratch) (void)hipFree(scratch);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
 int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int32_t *col, double *val, double *dinv,
                           int32_t *freeid) {
     if (!ctx) return REMO_ERR_ARG;
-    if (!b || !b->has_system) return fail(ctx, REMO_ERR_ARG, "no assembled system on this batch (run it first)");
+    if (!b || !b->has_system || b->run_id != ctx->run_id) return fail(ctx, REMO_ERR_ARG, "no assembled system on this batch (run it first)");
     try {
         HIP_TRY(hipSetDevice(ctx->device));
         const DeviceSymbolic &sy = b->sym;
@@ -556,7 +606,8 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int
 
 int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x, double *y, int32_t reps, double *ms_avg) {
     if (!ctx) return REMO_ERR_ARG;
-    if (!b || !b->has_system || !x || !y || k < 1 || k > REMO_MAX_RHS || reps < 1) return fail(ctx, REMO_ERR_ARG, "bad argument");
+    if (!b || !b->has_system || b->run_id != ctx->run_id || !x || !y || k < 1 || k > REMO_MAX_RHS || reps < 1)
+        return fail(ctx, REMO_ERR_ARG, "bad argument");
     double *dx = nullptr, *dy = nullptr;
     try {
         HIP_TRY(hipSetDevice(ctx->device));

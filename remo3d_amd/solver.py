@@ -145,6 +145,15 @@ class Batch:
             raise RemoError(rc, self.ctx.last_error())
         return [out[eval_ptr[k]:eval_ptr[k + 1]] for k in range(self.n_rhs)]
 
+    def eval(self, rhs: int, z):
+        """u_h of right-hand side `rhs` of the last run at further axis points (remo_batch_eval)."""
+        z = np.ascontiguousarray(np.atleast_1d(z), dtype=np.float64)
+        out = np.full(z.size, np.nan)
+        rc = self._L.remo_batch_eval(self.ctx._h, self._h, int(rhs), z.size, ptr(z, C.c_double), ptr(out, C.c_double))
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        return out
+
     def system(self):
         """CSR system of the last run: (rowptr, col, val, dinv, freeid)."""
         s = self.stats

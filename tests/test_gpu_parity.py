@@ -116,3 +116,42 @@ def test_error_paths_fill_nan(mesh2d, gpu_ctx):
     # zero-strength sources are skipped (ngsolve_functions.py:43): all-zero RHS gives u == 0
     outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, [([0.0], [0.0])], [[0.4]], solver.make_opts(), raise_on_error=False)
     assert rc == 0 and outs[0][0] == 0.0
+
+
+def test_solvebvp_plugin_interface_matches_batch(mesh3d, gpu_ctx):
+    """The per-RHS module interface of the reference (worker.py:100-131) gives the same potentials
+    as the batch call."""
+    from remo3d_amd import ngsolve_functions_hip as ngsf
+    from remo3d_amd import solver
+    mesh = ngsf.Mesh(mesh3d)
+    sigma = ngsf.CoefficientFunction(SIGMA3)
+    fes, gfu = ngsf.SolveBVP(mesh, sigma, np.array([-0.3, 0.0, 2.0]), np.array([0.0, 1.0, 0.0]), "dirichlet_boundary", "local", True)
+    assert fes.ndof > fes.nfree > 0
+    got = np.array([gfu(mesh(0.0, 0.0, z)) for z in (0.4, 6.4, -2.0)])
+    ref, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, [([0.0], [1.0])], [[0.4, 6.4, -2.0]], solver.make_opts(preconditioner="local"))
+    assert rc == 0 and np.allclose(got, ref[0], rtol=1e-12)
+    with pytest.raises(solver.RemoError):
+        gfu(mesh(0.0, 0.0, 75.0))          # outside the domain
+
+
+def test_model_end_to_end_example_01(examples_dir, gpu_ctx):
+    """Model.compute_synthetic_logs on the reference's Example_01 inputs against its committed
+    output log.  The meshes differ (seeded in-repo mesher with centroid materials vs the reference's
+    conforming Netgen mesh), so the tolerance is a mesh tolerance, not the 1e-6 solver tolerance:
+    the reference's own two runs (Example_01 vs 02) differ by up to 3.1e-4, median 2e-5."""
+    import os
+    from remo3d_amd.model import Model
+    tools = ["B5.7A0.4M", "B4.48A1.62M", "M1.0A0.1B", "A2.0M0.5N", "N0.5M2.0A", "M4.0A0.5B"]
+    gold = np.loadtxt(os.path.join(examples_dir, "Example_01/Output/Results_2024_08_17__18_59_29/Results_1.txt"), skiprows=2)
+    depths = np.arange(0, 25.1, 2.5)
+    m = Model.compute_synthetic_logs(tools, depths, os.path.join(examples_dir, "Example_01/Input/Formation.txt"),
+                                     os.path.join(examples_dir, "Example_01/Input/Borehole.txt"), gpu_workers=1, mesh_scale=0.7, verbose=False)
+    rows = np.rint(depths / 0.1).astype(int)
+    rel = []
+    for i, t in enumerate(tools):
+        assert np.all(np.isfinite(m.logs[t][:, 1]))
+        rel.append(np.abs(m.logs[t][:, 1] - gold[rows, 1 + i]) / gold[rows, 1 + i])
+    rel = np.array(rel)
+    print("Example_01 vs reference log: median rel diff %.2e, max %.2e" % (np.median(rel), rel.max()))
+    # measured: median 1.0e-2, max 4.7e-2 (borehole wall resolved by one element layer, materials by centroid)
+    assert np.median(rel) < 2e-2 and rel.max() < 1e-1

@@ -1,0 +1,49 @@
+import numpy as np
+import pytest
+
+from remo3d_amd import meshgen
+
+
+@pytest.mark.parametrize("dim,scale", [(2, 1.5), (3, 8.0)])
+def test_mesh_is_a_valid_seeded_triangulation_of_the_domain(dim, scale):
+    R = 50.0
+    m = meshgen.make_mesh(dim, R, [0.0, 0.2], scale=scale, seed=3)
+    m2 = meshgen.make_mesh(dim, R, [0.0, 0.2], scale=scale, seed=3)
+    assert np.array_equal(m.conn, m2.conn) and np.array_equal(m.coords, m2.coords)          # seeded
+    assert 0.95 < m.meta["volume"] / m.meta["volume_exact"] <= 1.0 + 1e-12                    # polyhedral approximation from inside
+    X = m.coords
+    rad = np.sqrt((X ** 2).sum(1))
+    assert rad.max() <= R * (1 + 1e-12)
+    assert (X[:, 0] >= 0).all() if dim == 2 else (X[:, 1] >= 0).all()
+    # Dirichlet facets are exactly the ones on the sphere; the rest lie on the axis / symmetry plane
+    bf, bd = m.bconn, m.bdirichlet.astype(bool)
+    assert np.all(rad[bf[bd]] >= R * (1 - 1e-9))
+    assert np.abs(X[bf[~bd]][:, :, 0 if dim == 2 else 1]).max() == 0.0
+    # closed boundary: every boundary ridge is shared by exactly two boundary facets
+    if dim == 3:
+        e = np.sort(np.concatenate([bf[:, [0, 1]], bf[:, [0, 2]], bf[:, [1, 2]]]), axis=1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        assert set(cnt) == {2}
+    # electrodes are vertices on the axis
+    ax = (X[:, 0] == 0) & ((X[:, 1] == 0) if dim == 3 else True)
+    for z in (0.0, 0.2):
+        assert np.abs(X[ax, dim - 1] - z).min() == 0.0
+    # graded: smallest edges near the sources, size field respected within a small factor
+    c = X[m.conn].mean(1)
+    h = meshgen.size_field(c, dim, [0.0, 0.2], scale)
+    P = X[m.conn]
+    emax = np.max([np.sqrt(((P[:, i] - P[:, j]) ** 2).sum(1)) for i in range(dim + 1) for j in range(i + 1, dim + 1)], axis=0)
+    assert np.percentile(emax / np.minimum(h, 0.2 * R), 99) < 4.0
+
+
+def test_layered_material_classifier_orders_zones_like_the_reference():
+    # two layers, the second with a flushed zone: materials 0 mud | 1 layer-1 | 2 flushed | 3 undisturbed
+    fg = np.array([[-60.0, 1.0, np.nan], [1.0, 60.0, 0.5]])
+    bh = np.array([[-50.0, 0.1], [50.0, 0.1]])
+    fn = meshgen.layered_material_fn(3, fg, bh, dip_rad=0.0)
+    c = np.array([[0.05, 0.01, -3.0], [0.3, 0.0, -3.0], [0.3, 0.1, 2.0], [0.7, 0.0, 2.0], [0.05, 0.0, 2.0]])
+    assert fn(c).tolist() == [0, 1, 2, 3, 0]
+    # dipping boundary: the plane z + tan(dip) x = 1 (slab rotated about y, gmsh_functions.py:610-611)
+    fn30 = meshgen.layered_material_fn(3, fg, bh, dip_rad=np.deg2rad(30))
+    assert fn30(np.array([[2.0, 0.0, 0.5]])).tolist() == [3]      # 0.5 + tan30*2 = 1.65 > 1 -> lower layer, outside fz
+    assert fn30(np.array([[-2.0, 0.0, 1.5]])).tolist() == [1]     # 1.5 - 1.15 = 0.35 < 1 -> upper layer

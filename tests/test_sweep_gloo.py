@@ -1,0 +1,53 @@
+"""N > 1 path of the depth sweep on CPU: two ranks, gloo backend (the RCCL path uses the same
+torch.distributed calls with backend "nccl")."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_share_is_block_cyclic_and_complete():
+    from remo3d_amd import sweep
+    for n in (0, 1, 7, 40):
+        for w in (1, 2, 3, 8):
+            shares = [list(sweep.my_share(n, r, w)) for r in range(w)]
+            assert sorted(i for s in shares for i in s) == list(range(n))
+            assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+
+
+def test_two_rank_sweep_combines_logs(tmp_path):
+    out = str(tmp_path / "res")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sweep_worker.py"), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [json.load(open(f"{out}.{k}")) for k in range(2)]
+    assert res[0]["world"] == 2 and {res[0]["rank"], res[1]["rank"]} == {0, 1}
+    # disjoint block-cyclic shares that cover all batches; every rank only solved its own share
+    all_b = sorted(res[0]["share"] + res[1]["share"])
+    assert all_b == list(range(len(all_b))) and res[0]["share"][0] == 0 and res[1]["share"][0] == 1
+    assert res[0]["calls"] == len(res[0]["share"]) - (1 if 3 in res[0]["share"] else 0) or res[0]["calls"] == len(res[0]["share"])
+    # both ranks hold the same, complete logs after the all-reduce
+    for tool in res[0]["logs"]:
+        a = np.array(res[0]["logs"][tool]); b = np.array(res[1]["logs"][tool])
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.allclose(a, b, equal_nan=True, rtol=0, atol=0)
+        good = ~np.isnan(a[:, 1])
+        assert np.allclose(a[good, 1], 7.0, rtol=1e-12)        # homogeneous medium: Ra == R (remo3d.py:285-306)
+    # the injected failure of batch 3 became NaN for exactly its records (worker.py:135-138)
+    n_nan = sum(int(np.isnan(np.array(v)[:, 1]).sum()) for v in res[0]["logs"].values())
+    assert 0 < n_nan <= 4 * 3

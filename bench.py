@@ -10,7 +10,7 @@ Batch meshes are seeded synthetic half-ball meshes with the reference's size fie
 the image); their sizes (T, n, nnz) are printed in the JSON line.
 
 One "step" = one pass of the hot path over every batch of this rank's share: dof numbering,
-CSR pattern, assembly, multi-RHS Jacobi-PCG, axis evaluation, apparent resistivity — then ONE
+CSR pattern, assembly, multi-RHS two-level PCG, axis evaluation, apparent resistivity — then ONE
 all-reduce of the log slab across ranks (RCCL).  Mesh arrays, sigma and points are resident on
 the device before the timed region (remo_batch_create); mesh generation is excluded, as SURVEY.md
 section 8d defines the point.
@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", default="M", choices=list(SIZES))
+    ap.add_argument("--size", default="S", choices=list(SIZES))
     ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxsteps", type=int, default=1000)
@@ -93,7 +93,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # REMO_DEVICE: rehearsals on a 1-GPU box
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     from remo3d_amd import solver, sweep, tasks
@@ -101,7 +101,8 @@ def main():
     if world > 1:
         import torch
         dist_on = sweep.init_from_env()
-        torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
 
     wl = build_workload(rank, world, args.depths, SIZES[args.size])
     work = wl["work"]
@@ -141,7 +142,8 @@ def main():
         if dist_on:
             import torch
             sweep.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
@@ -167,7 +169,7 @@ def main():
                config=dict(workload=f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
                            batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
                            mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, preconditioner="jacobi", max_pcg_iterations=int(agg["max_it"]),
+                           maxsteps=args.maxsteps, preconditioner="multigrid = Chebyshev(6) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
                            batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline,
                breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],

@@ -54,13 +54,16 @@ typedef struct {
 
 /* Solver options; zero-initialise then call remo_opts_default(). */
 typedef struct {
-    int32_t preconditioner; /* 0 = "local" (Jacobi, ngsolve_functions.py:46); 1 = "multigrid" => best available */
+    int32_t preconditioner; /* 0 = "local" (Jacobi, ngsolve_functions.py:46); 1 = "multigrid": two-level, Chebyshev
+                               solve of the P1 (vertex) block + Jacobi on edge/face dofs                  */
     int32_t condense;       /* static condensation of the 2D cell bubble (ngsolve_functions.py:31) */
     int32_t maxsteps;       /* CG step limit, reference 1000 (ngsolve_functions.py:50)             */
     int32_t check_every;    /* host looks at the residual history every this many steps            */
     double rtol;            /* stop when sqrt(<Cr,r>) <= rtol * sqrt(<Cr0,r0>); NGSolve default 1e-8 */
     int32_t time_kernels;   /* 1 = bracket every SpMV launch with HIP events (bench roofline)      */
-    int32_t reserved[5];
+    int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default 6) */
+    int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default 15) */
+    int32_t reserved[3];
 } remo_opts_t;
 
 typedef struct {

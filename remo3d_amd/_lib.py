@@ -24,7 +24,7 @@ class RemoMesh(C.Structure):
 class RemoOpts(C.Structure):
     _fields_ = [("preconditioner", C.c_int32), ("condense", C.c_int32), ("maxsteps", C.c_int32),
                 ("check_every", C.c_int32), ("rtol", C.c_double), ("time_kernels", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("coarse_degree", C.c_int32), ("coarse_ratio", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class RemoStats(C.Structure):

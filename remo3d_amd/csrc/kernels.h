@@ -22,6 +22,12 @@ struct PcgBuffers {
     double *part_pq;        // [kMaxPartialBlocks*8] per-workgroup partial sums of <p, Ap>
     double *part_rz;        // [2][kMaxPartialBlocks*8] per-workgroup partial sums of <Cr, r> (even / odd step)
     double *rz0;            // [8] device copy of <Cr0,r0>
+    // two-level preconditioner (vertex-block Chebyshev); cheb_degree = 0 -> Jacobi
+    int64_t nv_coarse;      // free vertex dofs = size of the leading P1 block
+    int cheb_degree;
+    double cheb_lmax, cheb_lmin;
+    double *cz, *cres;      // [nv_coarse*k]
+    double *cd[2];          // [nv_coarse*k] ping-pong Chebyshev directions
     PcgProgress *progress;  // mapped host ring [progress_len]
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
@@ -48,9 +54,11 @@ int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
 void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nblocks, hipStream_t s);
 
-void launch_pcg_init(int64_t n, int k, const double *f, const PcgBuffers &b, hipStream_t s);
-void launch_pcg_update(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
-void launch_pcg_direction(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
+void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers &b, hipStream_t s);       // + C r0, p0
+void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);  // + C r (Chebyshev steps)
+void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
+void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s);
+int cheb_grid(int64_t nv);
 void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s);
 
 // point location on the borehole axis + shape values; found[] must be pre-set to INT_MAX

@@ -453,8 +453,23 @@ void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *pa
 // A column whose <Cr,r> has dropped below tol^2 <Cr0,r0> (or that broke down) is frozen
 // (alpha = beta = 0), which makes post-convergence steps harmless.
 
+// Two-level preconditioner ("multigrid" of the reference, ngsolve_functions.py:46: a lowest-order
+// coarse space plus a smoother on the high-order dofs).  In the hierarchical basis the vertex
+// functions ARE the P1 space and vertex dofs are numbered first, so the coarse problem is the leading
+// nv x nv block of the assembled matrix, read in place (columns are sorted: the block's entries
+// lead every row).  C = blockdiag( q_d(A_vv), D_hh^-1 ): a fixed Chebyshev polynomial of degree d in
+// the Jacobi-scaled vertex block (spectrum bounds [lmax/ratio, lmax], lmax = Gershgorin bound, so
+// q_d is positive definite on the whole spectrum and plain PCG stays valid) and Jacobi on edge/face
+// dofs.  nv = 0 gives plain Jacobi ("local").
+struct ChebArgs {
+    int64_t nv;       // free vertex dofs (0: Jacobi)
+    double inv_theta; // 1 / theta, theta = (lmax + lmin) / 2
+    double *z, *res;  // [nv][K] polynomial value so far / residual of the vertex block system
+    double *d0;       // [nv][K] first Chebyshev direction
+};
+
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_init(int64_t n, const double *__restrict__ f, const double *__restrict__ dinv,
+__global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgs ch, const double *__restrict__ f, const double *__restrict__ dinv,
                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                   double *__restrict__ part_rz) {
     __shared__ double smem[16 * K];
@@ -463,14 +478,21 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t n, const double *__res
     for (int c = 0; c < K; ++c) rz[c] = 0.0;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const double d = dinv[i];
+        const bool coarse = i < ch.nv;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const double ri = f[i * K + c];
             const double zi = d * ri;
             x[i * K + c] = 0.0;
             r[i * K + c] = ri;
-            p[i * K + c] = zi;
-            rz[c] += ri * zi;
+            p[i * K + c] = coarse ? 0.0 : zi;
+            if (coarse) {
+                ch.z[i * K + c] = 0.0;
+                ch.res[i * K + c] = ri;
+                ch.d0[i * K + c] = zi * ch.inv_theta;
+            } else {
+                rz[c] += ri * zi;
+            }
         }
     }
     block_sum<K>(rz, smem);
@@ -478,7 +500,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t n, const double *__res
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int nb_spmv, int nb_vec,
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int nb_spmv, int nb_rz, ChebArgs ch,
                                                     const double *__restrict__ part_pq, const double *__restrict__ part_rz_cur,
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const double *__restrict__ p,
@@ -486,25 +508,9 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     const double *__restrict__ dinv) {
     __shared__ double smem[16 * K];
     double pq[K], rz[K], alpha[K], acc[K];
-    // issue this thread's first rows BEFORE the scalar reduction: the step length does not affect
-    // the addresses, so the vector loads fly while the workgroup re-reduces the partial sums
-    constexpr int PF = 2;
-    const int64_t gtid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
-    double pv[PF][K], qv[PF][K], xv[PF][K], rv[PF][K], dv[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t i = gtid + u * nthreads;
-        if (i < n) {
-            dv[u] = dinv[i];
-#pragma unroll
-            for (int c = 0; c < K; ++c) {
-                pv[u][c] = p[i * K + c]; qv[u][c] = q[i * K + c]; xv[u][c] = x[i * K + c]; rv[u][c] = r[i * K + c];
-            }
-        }
-    }
     reduce_partials<K>(part_pq, nb_spmv, pq, smem);
     __syncthreads();
-    reduce_partials<K>(part_rz_cur, nb_vec, rz, smem);
+    reduce_partials<K>(part_rz_cur, nb_rz, rz, smem);
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         const double r0 = (step == 0) ? rz[c] : rz0[c];
@@ -522,23 +528,9 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t i = gtid + u * nthreads;
-        if (i < n) {
-#pragma unroll
-            for (int c = 0; c < K; ++c) {
-                const double a = alpha[c];
-                const double xi = xv[u][c] + a * pv[u][c];
-                const double ri = rv[u][c] - a * qv[u][c];
-                x[i * K + c] = xi;
-                r[i * K + c] = ri;
-                acc[c] += ri * ri * dv[u];
-            }
-        }
-    }
-    for (int64_t i = gtid + PF * nthreads; i < n; i += nthreads) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const double d = dinv[i];
+        const bool coarse = i < ch.nv;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const double a = alpha[c];
@@ -546,7 +538,13 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             const double ri = r[i * K + c] - a * q[i * K + c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
-            acc[c] += ri * ri * d;
+            if (coarse) {  // start of the Chebyshev recurrence on the vertex block
+                ch.z[i * K + c] = 0.0;
+                ch.res[i * K + c] = ri;
+                ch.d0[i * K + c] = d * ri * ch.inv_theta;
+            } else {
+                acc[c] += ri * ri * d;
+            }
         }
     }
     __syncthreads();
@@ -554,56 +552,96 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
     if (threadIdx.x < K) part_rz_next[blockIdx.x * K + threadIdx.x] = acc[threadIdx.x];
 }
 
+// One Chebyshev step on the vertex block, 8 lanes per row:
+//   z += d;  res -= A_vv d;  d' = c1 d + c2 D^-1 res        (d' skipped and <r, z> partials left when LAST)
+template <int K, bool LAST>
+__global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, const double *__restrict__ dinv,
+                                                   const double *__restrict__ d_old, double *__restrict__ d_new,
+                                                   double *__restrict__ z, double *__restrict__ res, double c1, double c2,
+                                                   const double *__restrict__ r, double *__restrict__ part) {
+    constexpr int LPR = 8, RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    double dot[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
+        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        double t[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) t[c] = 0.0;
+        for (int32_t p = rs + sub; p < re; p += LPR) {
+            const int32_t j = col[p];
+            if (j >= nv) break;  // columns ascend: the vertex block leads the row
+            const double v = val[p];
+            const double *dj = d_old + int64_t(j) * K;
+#pragma unroll
+            for (int c = 0; c < K; ++c) t[c] += v * dj[c];
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) t[c] = group_sum<LPR>(t[c]);
+        if (sub == 0) {
+            const double di = dinv[row];
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const double dold = d_old[row * K + c];
+                const double zi = z[row * K + c] + dold;
+                const double ri = res[row * K + c] - t[c];
+                z[row * K + c] = zi;
+                res[row * K + c] = ri;
+                if (!LAST) d_new[row * K + c] = c1 * dold + c2 * di * ri;
+                if (LAST) dot[c] += r[row * K + c] * zi;
+            }
+        }
+    }
+    if (LAST) {
+        __shared__ double smem[16 * K];
+        block_sum<K>(dot, smem);
+        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = dot[threadIdx.x];
+    }
+}
+
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, double tol2, int nb_spmv, int nb_vec,
+__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, double tol2, int nb_spmv, int nb_rz, ChebArgs ch,
                                                        const double *__restrict__ part_pq, const double *__restrict__ part_rz_old,
                                                        const double *__restrict__ part_rz_new, const double *__restrict__ rz0,
                                                        const double *__restrict__ r, double *__restrict__ p,
                                                        const double *__restrict__ dinv) {
     __shared__ double smem[16 * K];
-    double pq[K], rzo[K], rzn[K], beta[K];
-    constexpr int PF = 2;  // rows in flight per thread while the partial sums are re-reduced
-    const int64_t gtid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nthreads = int64_t(gridDim.x) * blockDim.x;
-    double pv[PF][K], rv[PF][K], dv[PF];
+    double beta[K];
+    if (first) {  // p0 = C r0
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t i = gtid + u * nthreads;
-        if (i < n) {
-            dv[u] = dinv[i];
+        for (int c = 0; c < K; ++c) beta[c] = 0.0;
+    } else {
+        double pq[K], rzo[K], rzn[K];
+        reduce_partials<K>(part_pq, nb_spmv, pq, smem);
+        __syncthreads();
+        reduce_partials<K>(part_rz_old, nb_rz, rzo, smem);
+        __syncthreads();
+        reduce_partials<K>(part_rz_new, nb_rz, rzn, smem);
 #pragma unroll
-            for (int c = 0; c < K; ++c) { pv[u][c] = p[i * K + c]; rv[u][c] = r[i * K + c]; }
+        for (int c = 0; c < K; ++c) {
+            const bool live = (rzo[c] > tol2 * rz0[c]) && (pq[c] > 0.0);
+            beta[c] = live ? rzn[c] / rzo[c] : 0.0;
         }
     }
-    reduce_partials<K>(part_pq, nb_spmv, pq, smem);
-    __syncthreads();
-    reduce_partials<K>(part_rz_old, nb_vec, rzo, smem);
-    __syncthreads();
-    reduce_partials<K>(part_rz_new, nb_vec, rzn, smem);
-#pragma unroll
-    for (int c = 0; c < K; ++c) {
-        const bool live = (rzo[c] > tol2 * rz0[c]) && (pq[c] > 0.0);
-        beta[c] = live ? rzn[c] / rzo[c] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t i = gtid + u * nthreads;
-        if (i < n)
-#pragma unroll
-            for (int c = 0; c < K; ++c) p[i * K + c] = dv[u] * rv[u][c] + beta[c] * pv[u][c];
-    }
-    for (int64_t i = gtid + PF * nthreads; i < n; i += nthreads) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const double d = dinv[i];
+        const bool coarse = i < ch.nv;
 #pragma unroll
-        for (int c = 0; c < K; ++c) p[i * K + c] = d * r[i * K + c] + beta[c] * p[i * K + c];
+        for (int c = 0; c < K; ++c) {
+            const double zi = coarse ? ch.z[i * K + c] : d * r[i * K + c];
+            p[i * K + c] = first ? zi : zi + beta[c] * p[i * K + c];
+        }
     }
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_vec, const double *__restrict__ part_rz, PcgProgress *progress,
+__global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_rz, const double *__restrict__ part_rz, PcgProgress *progress,
                                                    int progress_len) {
     __shared__ double smem[16 * K];
     double rz[K];
-    reduce_partials<K>(part_rz, nb_vec, rz, smem);
+    reduce_partials<K>(part_rz, nb_rz, rz, smem);
     if (threadIdx.x == 0) {
         PcgProgress *pr = progress + (step % progress_len);
 #pragma unroll
@@ -612,10 +650,42 @@ __global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_vec, const d
     }
 }
 
+// Gershgorin bound of the Jacobi-scaled vertex block: max_i dinv_i * sum_j |a_ij|, j < nv
+__global__ void __launch_bounds__(256) k_vblock_bound(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const double *__restrict__ val, const double *__restrict__ dinv,
+                                                      unsigned long long *out_bits) {
+    double m = 0.0;
+    for (int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < nv; row += int64_t(gridDim.x) * blockDim.x) {
+        double s = 0.0;
+        for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+            if (col[p] >= nv) break;
+            s += fabs(val[p]);
+        }
+        m = fmax(m, s * dinv[row]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));  // positive doubles order like their bits
+}
+
+void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s) {
+    int64_t g = (nv + 255) / 256;
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_vblock_bound, dim3(int(g)), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, dinv, out_bits);
+}
+
 int vec_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
     if (g < 1) g = 1;
+    return int(g);
+}
+
+int cheb_grid(int64_t nv) {
+    if (nv <= 0) return 0;
+    int64_t g = (nv + 31) / 32;
+    if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
     return int(g);
 }
 
@@ -631,30 +701,76 @@ int vec_grid(int64_t n) {
         default: { constexpr int KK = 8; CALL; } break; \
     }
 
-void launch_pcg_init(int64_t n, int k, const double *f, const PcgBuffers &b, hipStream_t s) {
-    const int g = vec_grid(n);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_init<KK>, dim3(g), dim3(256), 0, s, n, f, b.dinv, b.x, b.r, b.p, b.part_rz));
+static ChebArgs cheb_args(const PcgBuffers &b) {
+    ChebArgs c;
+    c.nv = b.cheb_degree > 0 ? b.nv_coarse : 0;
+    c.inv_theta = b.cheb_degree > 0 ? 1.0 / (0.5 * (b.cheb_lmax + b.cheb_lmin)) : 0.0;
+    c.z = b.cz; c.res = b.cres; c.d0 = b.cd[0];
+    return c;
 }
 
-void launch_pcg_update(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
-    const int g = vec_grid(n);
+// C r for the vertex block: `degree` Chebyshev steps; the last one leaves the <r_v, z_v> partials
+// behind the nb_vec partials of the high-order part (slot = even / odd step buffer)
+static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *part_slot, hipStream_t s) {
+    if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
+    const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
+    const double sig = theta / delta;
+    double rho = 1.0 / sig;
+    const int g = cheb_grid(b.nv_coarse);
+    double *part = part_slot + int64_t(b.nb_vec) * k;
+    for (int j = 0; j < b.cheb_degree; ++j) {
+        const double rho_new = 1.0 / (2.0 * sig - rho);
+        const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+        rho = rho_new;
+        const double *dold = b.cd[j & 1];
+        double *dnew = b.cd[(j + 1) & 1];
+        if (j + 1 < b.cheb_degree) {
+            REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, false>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv,
+                                                dold, dnew, b.cz, b.cres, c1, c2, b.r, part));
+        } else {
+            REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, true>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv,
+                                                dold, dnew, b.cz, b.cres, c1, c2, b.r, part));
+        }
+    }
+}
+
+static int nb_rz(const PcgBuffers &b) { return b.nb_vec + ((b.cheb_degree > 0 && b.nv_coarse > 0) ? cheb_grid(b.nv_coarse) : 0); }
+
+void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers &b, hipStream_t s) {
+    const int64_t n = A.n;
+    const int g = b.nb_vec;
+    const ChebArgs ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_init<KK>, dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
+    launch_cheb(A, k, b, b.part_rz, s);
+    if (ch.nv > 0)
+        REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 1, 0.0, b.nb_spmv, nb_rz(b), ch, b.part_pq, b.part_rz,
+                                            b.part_rz, b.rz0, b.r, b.p, b.dinv));
+}
+
+void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
+    const int64_t n = A.n;
+    const int g = b.nb_vec;
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_update<KK>, dim3(g), dim3(256), 0, s, n, step, tol2, b.nb_spmv, g, b.part_pq, cur, nxt,
+    const ChebArgs ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_update<KK>, dim3(g), dim3(256), 0, s, n, step, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
+    launch_cheb(A, k, b, nxt, s);
 }
 
-void launch_pcg_direction(int64_t n, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
-    const int g = vec_grid(n);
+void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
+    const int64_t n = A.n;
+    const int g = b.nb_vec;
     const double *old = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, tol2, b.nb_spmv, g, b.part_pq, old, nw, b.rz0,
+    const ChebArgs ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 0, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, old, nw, b.rz0,
                                         b.r, b.p, b.dinv));
 }
 
 void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s) {
     const double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_final<KK>, dim3(1), dim3(256), 0, s, step, b.nb_vec, cur, b.progress, b.progress_len));
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_final<KK>, dim3(1), dim3(256), 0, s, step, nb_rz(b), cur, b.progress, b.progress_len));
 }
 
 // ------------------------------------------------------------------------------------------

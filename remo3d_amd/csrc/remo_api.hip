@@ -152,7 +152,7 @@ ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, P
     const int check = o.check_every > 0 ? o.check_every : 10;
     for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    launch_pcg_init(A.n, k, d_f, buf, s);
+    launch_pcg_init(A, k, d_f, buf, s);
     int step = 0;
     bool done = false;
     for (; step < maxit && !done;) {
@@ -164,8 +164,8 @@ ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, P
         } else {
             launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.nb_spmv, s);
         }
-        launch_pcg_update(A.n, k, step, tol2, buf, s);
-        launch_pcg_direction(A.n, k, step, tol2, buf, s);
+        launch_pcg_update(A, k, step, tol2, buf, s);
+        launch_pcg_direction(A, k, step, tol2, buf, s);
         ++step;
         if (step % check == 0) {
             const int target = step - 2 * check;  // stay two checks ahead of the device
@@ -221,6 +221,8 @@ void remo_opts_default(remo_opts_t *o) {
     o->check_every = 10;
     o->rtol = 1e-8;         // NGSolve CGSolver default precision
     o->time_kernels = 0;
+    o->coarse_degree = 6;
+    o->coarse_ratio = 15;
 }
 
 remo_ctx_t *remo_ctx_create(int device_id) {
@@ -379,7 +381,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // ---- device arena: numbering scratch + upper bounds of everything numeric ---------
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
-        need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax));
+        need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         ctx->reserve(need);
 
@@ -404,6 +406,14 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
         buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
         buf.rz0 = ctx->take<double>(8);
+        const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
+        buf.nv_coarse = two_level ? sy.nvfree : 0;
+        buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : 6) : 0;
+        buf.cheb_lmax = buf.cheb_lmin = 0.0;
+        const size_t nc = size_t(buf.nv_coarse) * kmax + 2;
+        buf.cz = ctx->take<double>(nc); buf.cres = ctx->take<double>(nc);
+        buf.cd[0] = ctx->take<double>(nc); buf.cd[1] = ctx->take<double>(nc);
+        unsigned long long *d_bound = ctx->take<unsigned long long>(2);
         double *d_pz = ctx->take<double>(npts + 1), *d_pI = ctx->take<double>(npts + 1);
         int32_t *d_prhs = ctx->take<int32_t>(npts + 1), *d_found = ctx->take<int32_t>(npts + 1);
         double *d_phi = ctx->take<double>(size_t(npts + 1) * N), *d_fint = ctx->take<double>(npts + 1), *d_out = ctx->take<double>(npts + 1);
@@ -442,8 +452,21 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         }
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         int32_t h_err = 0;
+        unsigned long long h_bound = 0;
+        if (two_level) {  // spectrum bound of the Jacobi-scaled vertex block for the Chebyshev interval
+            HIP_TRY(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long), s));
+            launch_vblock_bound(buf.nv_coarse, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, d_dinv, d_bound, s);
+            HIP_TRY(hipMemcpyAsync(&h_bound, d_bound, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (two_level) {
+            double lmax;
+            std::memcpy(&lmax, &h_bound, sizeof lmax);
+            if (!(lmax > 0.0) || !std::isfinite(lmax)) return fail(ctx, REMO_ERR_NUMERIC, "vertex block has no positive spectrum bound");
+            buf.cheb_lmax = lmax;
+            buf.cheb_lmin = lmax / double(o.coarse_ratio > 0 ? o.coarse_ratio : 15);
+        }
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
 

@@ -25,7 +25,7 @@ class RemoError(RuntimeError):
 
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=10,
-              time_kernels=False) -> RemoOpts:
+              time_kernels=False, coarse_degree=0, coarse_ratio=0) -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50)."""
     L = _lib.load()
     o = RemoOpts()
@@ -38,6 +38,8 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     o.rtol = float(rtol)
     o.check_every = int(check_every)
     o.time_kernels = 1 if time_kernels else 0
+    o.coarse_degree = int(coarse_degree)
+    o.coarse_ratio = int(coarse_ratio)
     return o
 
 

@@ -53,9 +53,9 @@ def init_from_env(backend: Optional[str] = None) -> bool:
     if dist.is_initialized():
         return True
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("REMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     dist.init_process_group(backend=backend)
     return True
 

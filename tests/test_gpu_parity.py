@@ -155,3 +155,26 @@ def test_model_end_to_end_example_01(examples_dir, gpu_ctx):
     print("Example_01 vs reference log: median rel diff %.2e, max %.2e" % (np.median(rel), rel.max()))
     # measured: median 1.0e-2, max 4.7e-2 (borehole wall resolved by one element layer, materials by centroid)
     assert np.median(rel) < 2e-2 and rel.max() < 1e-1
+
+
+@pytest.mark.parametrize("which", ["2d", "3d"])
+def test_two_level_preconditioner_same_solution_fewer_steps(which, mesh2d, mesh3d, gpu_ctx):
+    """preconditioner="multigrid" (vertex-block Chebyshev + Jacobi) changes the iteration, not the
+    solution: potentials agree with the Jacobi-PCG ("local") and with the oracle to 1e-8."""
+    from remo3d_amd import solver
+    mesh = mesh2d if which == "2d" else mesh3d
+    o, ref = _oracle_solve(mesh, SIGMA3, True)
+    res = {}
+    for pre in ("local", "multigrid"):
+        outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-12, maxsteps=20000))
+        assert rc == 0
+        res[pre] = (outs, max(st["iterations"][:3]))
+        for g, r in zip(outs, ref):
+            assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
+    print(which, "PCG steps: local", res["local"][1], "multigrid", res["multigrid"][1])
+    assert res["multigrid"][1] < res["local"][1]
+    # other degrees / intervals are valid preconditioners too
+    outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-12, maxsteps=20000, coarse_degree=3, coarse_ratio=5))
+    assert rc == 0
+    for g, r in zip(outs, ref):
+        assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))

@@ -52,12 +52,11 @@ print(f"n={n} nnz={nnz} k={k} algorithmic MB/launch={bytes_alg/1e6:.1f}")
 for i, c in enumerate(configs):
     ms = np.array(res[i])
     print(f"{json.dumps(c):80s} median {np.median(ms)*1e3:7.1f} us  min {ms.min()*1e3:7.1f} us  -> {bytes_alg/1e9/(np.median(ms)/1e3):7.0f} GB/s")
-# full solve timing (SpMM with the fused <p, Ap> reduction) under a few launch shapes
-for threads, grid in [(0, 0), (256, 1024), (256, 2048), (512, 1024), (512, 2048), (256, 512)]:
-    tune(0, 0, threads, -1, grid)
-    for rnd in range(2):
-        b.run(solver.make_opts(rtol=1e-8, time_kernels=True))
-    st = b.stats
-    print("solve threads=%d grid=%d: steps" % (threads, grid), st["pcg_steps"], "ms_solve %.2f" % st["ms_solve"], "us/step %.1f" % (1e3 * st["ms_solve"] / st["pcg_steps"]),
-          "spmv us %.1f" % (1e3 * st["spmv_ms"] / st["spmv_launches"]), "symbolic ms %.2f assemble ms %.2f" % (st["ms_symbolic"], st["ms_assemble"]))
+# full solve timing: Jacobi vs two-level with several Chebyshev degrees / intervals
 tune(0, 0, 0, -1, 0)
+for pre, deg, ratio in [("local", 0, 0), ("multigrid", 4, 8), ("multigrid", 6, 15), ("multigrid", 10, 30), ("multigrid", 16, 60), ("multigrid", 24, 150)]:
+    for rnd in range(2):
+        b.run(solver.make_opts(preconditioner=pre, rtol=1e-8, time_kernels=True, coarse_degree=deg, coarse_ratio=ratio))
+    st = b.stats
+    print("solve %s deg=%d ratio=%d: steps" % (pre, deg, ratio), st["pcg_steps"], "max its", st["max_iterations"], "ms_solve %.2f" % st["ms_solve"],
+          "us/step %.1f" % (1e3 * st["ms_solve"] / st["pcg_steps"]), "spmv us %.1f" % (1e3 * st["spmv_ms"] / st["spmv_launches"]))

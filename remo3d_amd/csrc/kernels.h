@@ -39,6 +39,9 @@ struct CsrView {
     const int32_t *rowptr;
     const int32_t *col;
     const double *val;
+    // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
+    // column patterns (0, 0 = unknown)
+    int64_t pair_begin = 0, pair_end = 0;
 };
 
 void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,

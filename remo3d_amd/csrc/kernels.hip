@@ -275,6 +275,94 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mappin
     }
 }
 
+// Variant C ("edge row pairs", the default): the two dofs of an edge are consecutive rows with the
+// SAME column pattern, and edge rows hold ~3/4 of the stored entries.  A lane group takes both
+// rows at once: one column index and ONE gather of the x row serve two stored entries.  Vertex and
+// face rows are walked singly.
+// The kernel is latency-bound, not bandwidth-bound (a stored entry costs two dependent memory
+// round trips: column index, then the x row), so each lane issues the index/value loads of U
+// passes of its row up front and then all U gathers, before any arithmetic: a row of <= U * LPR
+// entries pays the two latencies once instead of once per pass.  Lanes past the row end read a
+// safe address with a zero value (no branches between the loads).
+template <int K, int LPR, bool DOT>
+__global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+    constexpr int U = 2;
+    const int rpb = blockDim.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int grp = threadIdx.x / LPR;
+    const int64_t npair = (pair_end - pair_begin) >> 1;
+    const int64_t ngroups = n - npair;
+    double dot[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    for (int64_t g = int64_t(blockIdx.x) * rpb + grp; g < ngroups; g += int64_t(gridDim.x) * rpb) {
+        int64_t row;
+        bool pair = false;
+        if (g < pair_begin) row = g;
+        else if (g < pair_begin + npair) { row = pair_begin + 2 * (g - pair_begin); pair = true; }
+        else row = g + npair;
+        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        const int32_t len = pair ? re - rs : 0;   // the second row's values sit `len` entries further
+        double acc0[K], acc1[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
+        for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {
+            int32_t j[U];
+            double v0[U], v1[U], xv[U][K];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t p = p0 + u * LPR;
+                const bool ok = p < re;
+                const int32_t ps = ok ? p : rs;      // in-range address for idle lanes
+                j[u] = col[ps];
+                const double a = val[ps], b = val[ps + len];
+                v0[u] = ok ? a : 0.0;
+                v1[u] = ok ? b : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double *xr = x + int64_t(j[u]) * K;
+#pragma unroll
+                for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    acc0[c] += v0[u] * xv[u][c];
+                    acc1[c] += v1[u] * xv[u][c];
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc0[c] = group_sum<LPR>(acc0[c]);
+        if (pair)
+#pragma unroll
+            for (int c = 0; c < K; ++c) acc1[c] = group_sum<LPR>(acc1[c]);
+        if (sub == 0) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) y[row * K + c] = acc0[c];
+            if (pair)
+#pragma unroll
+                for (int c = 0; c < K; ++c) y[(row + 1) * K + c] = acc1[c];
+            if (DOT) {
+                const double *xr = x + row * K;
+#pragma unroll
+                for (int c = 0; c < K; ++c) dot[c] += acc0[c] * xr[c];
+                if (pair)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) dot[c] += acc1[c] * xr[K + c];
+            }
+        }
+    }
+    if (DOT) {
+        __shared__ double smem[16 * K];
+        block_sum<K>(dot, smem);
+        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
+    }
+}
+
 // Variant B ("chunk lanes"): a fully divergent gather costs the texture-address path one cache
 // line visit per lane and instruction, so K 8-byte loads per stored entry visit ~5 K lines per 64
 // entries.  Here LQ = 1/2/4 adjacent lanes share one stored entry and each loads ONE 16-byte chunk
@@ -365,7 +453,7 @@ __global__ void __launch_bounds__(512) k_spmm_chunk(int64_t n, int64_t nnz, int 
 
 // tuning knobs (remo_debug_tune): 0 = heuristic default
 struct SpmmTuning {
-    int variant = 0;  // 1 = lane per nonzero, 2 = chunk lanes
+    int variant = 0;  // 1 = lane per nonzero, 2 = chunk lanes, 3 = edge row pairs
     int lpr = 0;
     int threads = 0;
     int mapping = -1;
@@ -406,14 +494,25 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
     const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 0;
-    const int variant = g_tune.variant ? g_tune.variant : 1;
+    int variant = g_tune.variant ? g_tune.variant : 3;
+    if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
     constexpr int LQ = Chunks<K>::LQ;
 #define REMO_SPMM(KERNEL, L)                                                                                                          \
     if (part)                                                                                                                         \
         hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part); \
     else                                                                                                                              \
         hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part)
-    if (variant == 1) {
+#define REMO_SPMM_PAIR(L)                                                                                                               \
+    if (part)                                                                                                                           \
+        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part); \
+    else                                                                                                                                \
+        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part)
+    if (variant == 3) {
+        if (lpr >= 32) { REMO_SPMM_PAIR(32); }
+        else if (lpr == 16) { REMO_SPMM_PAIR(16); }
+        else if (lpr == 8) { REMO_SPMM_PAIR(8); }
+        else { REMO_SPMM_PAIR(4); }
+    } else if (variant == 1) {
         if (lpr >= 32) { REMO_SPMM(k_spmm, 32); }
         else if (lpr == 16) { REMO_SPMM(k_spmm, 16); }
         else if (lpr == 8) { REMO_SPMM(k_spmm, 8); }
@@ -427,6 +526,7 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
         else { REMO_SPMM(k_spmm_chunk, 4); }
     }
 #undef REMO_SPMM
+#undef REMO_SPMM_PAIR
 }
 
 void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nb, hipStream_t s) {

@@ -471,6 +471,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
+        if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { b->A.pair_begin = sy.nvfree; b->A.pair_end = sy.nvefree; }
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;

@@ -39,6 +39,7 @@ struct DeviceSymbolic {
     bool condense = false;
     int64_t nv = 0, nt = 0, ne = 0, nf = 0, ndof = 0, nfree = 0, nnz = 0, nadj = 0;
     int64_t nvfree = 0;  // free vertex dofs: rows/cols [0, nvfree) are the P1 block of the matrix
+    int64_t nvefree = 0; // free vertex + edge dofs: rows [nvfree, nvefree) are edge dofs, two consecutive rows per edge
     int32_t *conn = nullptr;    // [nt][dim+1] ascending per element
     int32_t *eldof = nullptr;   // [nt][nld_full] free row or -1
     int32_t *freeid = nullptr;  // [ndof]

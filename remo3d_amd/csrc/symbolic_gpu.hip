@@ -181,12 +181,13 @@ __global__ void __launch_bounds__(256) k_fill_i32(int64_t n, int32_t v, int32_t 
 
 // freeid = isfree ? scan : -1   (scan = exclusive prefix sum of isfree)
 __global__ void __launch_bounds__(256) k_freeid(int64_t n, const int32_t *__restrict__ isfree, const int32_t *__restrict__ scan,
-                                                int32_t *__restrict__ freeid, int32_t *__restrict__ nfree_out, int64_t nv) {
+                                                int32_t *__restrict__ freeid, int32_t *__restrict__ nfree_out, int64_t nv, int64_t nve) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     freeid[i] = isfree[i] ? scan[i] : -1;
     if (i == n - 1) nfree_out[0] = scan[i] + isfree[i];
     if (i == nv - 1) nfree_out[1] = scan[i] + isfree[i];  // free vertex dofs = leading block of the matrix
+    if (i == nve - 1) nfree_out[2] = scan[i] + isfree[i]; // free vertex + edge dofs: edge rows end here
 }
 
 // eldof: global dof -> free row (or -1); adjacency pairs; CSR keys
@@ -357,9 +358,9 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
         void *tmp = ar.hi<char>(tb + 256);
         HIP_OK(rocprim::exclusive_scan(tmp, tb, isfree, scan, int32_t(0), size_t(ndof), rocprim::plus<int32_t>(), s));
     }
-    hipLaunchKernelGGL(k_freeid, dim3(grid_for(ndof)), dim3(256), 0, s, ndof, isfree, scan, out.freeid, d_cnt, nv);
-    int32_t h_cnt[2] = {0, 0}, h_err = 0;
-    HIP_OK(hipMemcpyAsync(h_cnt, d_cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_freeid, dim3(grid_for(ndof)), dim3(256), 0, s, ndof, isfree, scan, out.freeid, d_cnt, nv, nv + 2 * ne);
+    int32_t h_cnt[3] = {0, 0, 0}, h_err = 0;
+    HIP_OK(hipMemcpyAsync(h_cnt, d_cnt, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_OK(hipMemcpyAsync(&h_err, d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     ar.hi_release(hi_mark1);
@@ -370,6 +371,7 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     if (nfree <= 0) { err = "no free dofs"; return REMO_ERR_MESH; }
     out.nfree = nfree;
     out.nvfree = h_cnt[1];
+    out.nvefree = h_cnt[2];
 
     // ---- element rows, adjacency --------------------------------------------------------------
     const int64_t npairs = nt * nld;

@@ -33,7 +33,7 @@ def tune(variant, lpr, threads, mapping, grid):
 
 configs = []
 for variant, lpr, threads, mapping, grid in [
-    (1, 16, 256, 0, 1024), (1, 16, 256, 0, 2048), (1, 16, 512, 0, 2048), (1, 16, 256, 1, 2048), (1, 8, 256, 0, 2048), (1, 32, 256, 0, 2048),
+    (1, 16, 256, 0, 1024), (3, 16, 256, 0, 1024), (3, 8, 256, 0, 1024), (3, 32, 256, 0, 1024), (3, 16, 512, 0, 1024), (3, 16, 256, 0, 512), (3, 8, 512, 0, 1024),
 ]:
     configs.append(dict(variant=variant, lpr=lpr, threads=threads, mapping=mapping, grid=grid))
 
@@ -54,7 +54,7 @@ for i, c in enumerate(configs):
     print(f"{json.dumps(c):80s} median {np.median(ms)*1e3:7.1f} us  min {ms.min()*1e3:7.1f} us  -> {bytes_alg/1e9/(np.median(ms)/1e3):7.0f} GB/s")
 # full solve timing: Jacobi vs two-level with several Chebyshev degrees / intervals
 tune(0, 0, 0, -1, 0)
-for pre, deg, ratio in [("local", 0, 0), ("multigrid", 4, 8), ("multigrid", 6, 15), ("multigrid", 10, 30), ("multigrid", 16, 60), ("multigrid", 24, 150)]:
+for pre, deg, ratio in [("local", 0, 0), ("multigrid", 4, 8), ("multigrid", 6, 15), ("multigrid", 8, 20)]:
     for rnd in range(2):
         b.run(solver.make_opts(preconditioner=pre, rtol=1e-8, time_kernels=True, coarse_degree=deg, coarse_ratio=ratio))
     st = b.stats

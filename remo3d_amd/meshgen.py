@@ -262,7 +262,11 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
             mv = ~pinned[v]
             step = (rng.random((int(mv.sum()), dim)) - 0.5) * 0.5 * hb[mv][:, None]
             step[on_plane[v[mv]], 1] = 0.0     # symmetry-plane vertices move in their plane
-            pts[v[mv]] += step
+            cand = pts[v[mv]] + step
+            # a move must keep the vertex strictly inside the half ball (a point pushed through the
+            # symmetry plane or the sphere would become a hull vertex and wreck the triangulation)
+            inside = (np.sqrt((cand ** 2).sum(1)) < R - 0.5 * hb[mv]) & (on_plane[v[mv]] | (cand[:, 1] > 0.5 * hb[mv]))
+            pts[v[mv][inside]] = cand[inside]
         conn, vol, edges, qual = triangulate(pts)
     emax = edges.max(1)
 
@@ -278,6 +282,9 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     new_id = np.full(len(pts), -1, dtype=np.int64); new_id[order] = np.arange(order.size)
     pts = pts[order]; conn = new_id[conn]
 
+    valence = np.bincount(conn.ravel(), minlength=len(pts)).max()
+    if valence > 400:   # a vertex shared by hundreds of elements means the hull was broken
+        raise RuntimeError("mesh generation produced a degenerate triangulation (vertex valence %d)" % valence)
     bf = _boundary_facets(conn)
     rad = np.sqrt((pts ** 2).sum(1))
     bdir = np.all(rad[bf] >= R * (1 - 1e-9), axis=1)
@@ -285,7 +292,8 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     mat = np.zeros(len(conn), dtype=np.int32) if material_fn is None else np.asarray(material_fn(cent), dtype=np.int32)
     exact = (np.pi * R * R / 2) if dim == 2 else (2.0 / 3.0 * np.pi * R ** 3)
     meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z],
-                volume=float(vol.sum()), volume_exact=float(exact), min_quality=float(qual.min()))
+                volume=float(vol.sum()), volume_exact=float(exact), min_quality=float(qual.min()),
+                max_valence=int(valence))
     return Mesh(dim, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)),
                 np.ascontiguousarray(mat), np.ascontiguousarray(bf.astype(np.int32)),
                 np.ascontiguousarray(bdir.astype(np.uint8)), meta)

@@ -28,6 +28,8 @@ def test_mesh_is_a_valid_seeded_triangulation_of_the_domain(dim, scale):
     ax = (X[:, 0] == 0) & ((X[:, 1] == 0) if dim == 3 else True)
     for z in (0.0, 0.2):
         assert np.abs(X[ax, dim - 1] - z).min() == 0.0
+    # no slivers worth the name, no broken hull (sliver passes must keep every vertex inside the domain)
+    assert m.meta["min_quality"] > (0.2 if dim == 2 else 1e-3) and m.meta["max_valence"] < 120
     # graded: smallest edges near the sources, size field respected within a small factor
     c = X[m.conn].mean(1)
     h = meshgen.size_field(c, dim, [0.0, 0.2], scale)

@@ -59,6 +59,28 @@ template <int K> __device__ __forceinline__ void reduce_partials(const double *p
     for (int c = 0; c < K; ++c) out[c] = v[c];
 }
 
+// Up to three partial arrays reduced in ONE pass (one barrier pair instead of three): the loads of all
+// arrays are in flight together.  Arrays with n = 0 are skipped.  Fixed order: deterministic.
+template <int K>
+__device__ __forceinline__ void reduce_partials3(const double *pa, int na, const double *pb, int nb, const double *pc, int nc,
+                                                 double (&oa)[K], double (&ob)[K], double (&oc)[K], double *smem /* [16*3*K] */) {
+    double v[3 * K];
+#pragma unroll
+    for (int c = 0; c < 3 * K; ++c) v[c] = 0.0;
+    for (int b = threadIdx.x; b < na; b += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < K; ++c) v[c] += pa[b * K + c];
+    for (int b = threadIdx.x; b < nb; b += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < K; ++c) v[K + c] += pb[b * K + c];
+    for (int b = threadIdx.x; b < nc; b += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < K; ++c) v[2 * K + c] += pc[b * K + c];
+    block_sum<3 * K>(v, smem);
+#pragma unroll
+    for (int c = 0; c < K; ++c) { oa[c] = v[c]; ob[c] = v[K + c]; oc[c] = v[2 * K + c]; }
+}
+
 template <int K> __device__ __forceinline__ double pick(const double (&a)[K], int c) {
     double r = a[0];
 #pragma unroll
@@ -586,13 +608,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgs ch, const 
             x[i * K + c] = 0.0;
             r[i * K + c] = ri;
             p[i * K + c] = coarse ? 0.0 : zi;
-            if (coarse) {
-                ch.z[i * K + c] = 0.0;
-                ch.res[i * K + c] = ri;
-                ch.d0[i * K + c] = zi * ch.inv_theta;
-            } else {
-                rz[c] += ri * zi;
-            }
+            rz[c] += coarse ? 0.0 : ri * zi;   // the vertex block's share comes from the Chebyshev kernels
         }
     }
     block_sum<K>(rz, smem);
@@ -606,11 +622,9 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     PcgProgress *progress, int progress_len, const double *__restrict__ p,
                                                     const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ dinv) {
-    __shared__ double smem[16 * K];
-    double pq[K], rz[K], alpha[K], acc[K];
-    reduce_partials<K>(part_pq, nb_spmv, pq, smem);
-    __syncthreads();
-    reduce_partials<K>(part_rz_cur, nb_rz, rz, smem);
+    __shared__ double smem[16 * 3 * K];
+    double pq[K], rz[K], unused[K], alpha[K], acc[K];
+    reduce_partials3<K>(part_pq, nb_spmv, part_rz_cur, nb_rz, nullptr, 0, pq, rz, unused, smem);
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         const double r0 = (step == 0) ? rz[c] : rz0[c];
@@ -638,13 +652,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             const double ri = r[i * K + c] - a * q[i * K + c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
-            if (coarse) {  // start of the Chebyshev recurrence on the vertex block
-                ch.z[i * K + c] = 0.0;
-                ch.res[i * K + c] = ri;
-                ch.d0[i * K + c] = d * ri * ch.inv_theta;
-            } else {
-                acc[c] += ri * ri * d;
-            }
+            acc[c] += coarse ? 0.0 : ri * ri * d;   // the vertex block's share comes from the Chebyshev kernels
         }
     }
     __syncthreads();
@@ -653,12 +661,14 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 }
 
 // One Chebyshev step on the vertex block, 8 lanes per row:
-//   z += d;  res -= A_vv d;  d' = c1 d + c2 D^-1 res        (d' skipped and <r, z> partials left when LAST)
-template <int K, bool LAST>
+//   z += d;  res -= A_vv d;  d' = c1 d + c2 D^-1 res
+// FIRST: z = 0, res = r, d = D^-1 r / theta are formed on the fly from the PCG residual (no set-up
+// pass); LAST: d' is skipped and the <r, z> partial sums are left for the PCG scalars.
+template <int K, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const double *__restrict__ val, const double *__restrict__ dinv,
                                                    const double *__restrict__ d_old, double *__restrict__ d_new,
-                                                   double *__restrict__ z, double *__restrict__ res, double c1, double c2,
+                                                   double *__restrict__ z, double *__restrict__ res, double c1, double c2, double inv_theta,
                                                    const double *__restrict__ r, double *__restrict__ part) {
     constexpr int LPR = 8, RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
@@ -673,8 +683,8 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
         for (int32_t p = rs + sub; p < re; p += LPR) {
             const int32_t j = col[p];
             if (j >= nv) break;  // columns ascend: the vertex block leads the row
-            const double v = val[p];
-            const double *dj = d_old + int64_t(j) * K;
+            const double v = FIRST ? val[p] * dinv[j] * inv_theta : val[p];
+            const double *dj = (FIRST ? r : d_old) + int64_t(j) * K;
 #pragma unroll
             for (int c = 0; c < K; ++c) t[c] += v * dj[c];
         }
@@ -684,13 +694,16 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
             const double di = dinv[row];
 #pragma unroll
             for (int c = 0; c < K; ++c) {
-                const double dold = d_old[row * K + c];
-                const double zi = z[row * K + c] + dold;
-                const double ri = res[row * K + c] - t[c];
-                z[row * K + c] = zi;
-                res[row * K + c] = ri;
-                if (!LAST) d_new[row * K + c] = c1 * dold + c2 * di * ri;
-                if (LAST) dot[c] += r[row * K + c] * zi;
+                const double rr = r[row * K + c];
+                const double dold = FIRST ? di * rr * inv_theta : d_old[row * K + c];
+                const double zi = FIRST ? dold : z[row * K + c] + dold;
+                const double ri = (FIRST ? rr : res[row * K + c]) - t[c];
+                z[row * K + c] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
+                if (!LAST) {
+                    res[row * K + c] = ri;
+                    d_new[row * K + c] = c1 * dold + c2 * di * ri;
+                }
+                if (LAST) dot[c] += rr * zi;
             }
         }
     }
@@ -707,18 +720,14 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, dou
                                                        const double *__restrict__ part_rz_new, const double *__restrict__ rz0,
                                                        const double *__restrict__ r, double *__restrict__ p,
                                                        const double *__restrict__ dinv) {
-    __shared__ double smem[16 * K];
+    __shared__ double smem[16 * 3 * K];
     double beta[K];
     if (first) {  // p0 = C r0
 #pragma unroll
         for (int c = 0; c < K; ++c) beta[c] = 0.0;
     } else {
         double pq[K], rzo[K], rzn[K];
-        reduce_partials<K>(part_pq, nb_spmv, pq, smem);
-        __syncthreads();
-        reduce_partials<K>(part_rz_old, nb_rz, rzo, smem);
-        __syncthreads();
-        reduce_partials<K>(part_rz_new, nb_rz, rzn, smem);
+        reduce_partials3<K>(part_pq, nb_spmv, part_rz_old, nb_rz, part_rz_new, nb_rz, pq, rzo, rzn, smem);
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const bool live = (rzo[c] > tol2 * rz0[c]) && (pq[c] > 0.0);
@@ -727,10 +736,10 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, dou
     }
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const double d = dinv[i];
-        const bool coarse = i < ch.nv;
+        const double *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            const double zi = coarse ? ch.z[i * K + c] : d * r[i * K + c];
+            const double zi = d * src[i * K + c];
             p[i * K + c] = first ? zi : zi + beta[c] * p[i * K + c];
         }
     }
@@ -814,7 +823,7 @@ static ChebArgs cheb_args(const PcgBuffers &b) {
 static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *part_slot, hipStream_t s) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
     const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
-    const double sig = theta / delta;
+    const double sig = theta / delta, inv_theta = 1.0 / theta;
     double rho = 1.0 / sig;
     const int g = cheb_grid(b.nv_coarse);
     double *part = part_slot + int64_t(b.nb_vec) * k;
@@ -824,13 +833,15 @@ static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *pa
         rho = rho_new;
         const double *dold = b.cd[j & 1];
         double *dnew = b.cd[(j + 1) & 1];
-        if (j + 1 < b.cheb_degree) {
-            REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, false>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv,
-                                                dold, dnew, b.cz, b.cres, c1, c2, b.r, part));
-        } else {
-            REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, true>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv,
-                                                dold, dnew, b.cz, b.cres, c1, c2, b.r, part));
-        }
+        const bool first = (j == 0), last = (j + 1 == b.cheb_degree);
+#define REMO_CHEB(F, L)                                                                                                                          \
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
+                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part))
+        if (first && last) { REMO_CHEB(true, true); }
+        else if (first) { REMO_CHEB(true, false); }
+        else if (last) { REMO_CHEB(false, true); }
+        else { REMO_CHEB(false, false); }
+#undef REMO_CHEB
     }
 }
 

@@ -78,6 +78,19 @@ def cpu_baseline(work, rtol, budget_rhs=1):
                        "NGSolve is not installable here, so this is the build's scalar C restatement, not the reference binary"), out
 
 
+def pmc_traffic(workload, n_free, nnz):
+    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this exact workload (profiles/, collected with tools/pmc_traffic.py); None when the run differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_default_bench.json")) as f:
+            p = json.load(f)
+    except OSError:
+        return None
+    if p.get("workload") == workload and p.get("n_free") == n_free and p.get("nnz") == nnz:
+        return p["spmm"]["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,10 +172,12 @@ def main():
     if rank != 0:
         return
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
-    roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None, traffic=None,
+    roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
+                    traffic=pmc_traffic(f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
+                                        int(agg["n"]), int(agg["nnz"])),
                     kernel="k_spmm (CSR SpMM, fp64, k=5 interleaved RHS)", launches=int(agg["spmv_launches"]),
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
-                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)")
+                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)", traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_b_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f64", data="synthetic",

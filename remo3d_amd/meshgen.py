@@ -156,7 +156,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
               material_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None, seed: int = 0,
               h_axis: float = 0.1, h_src: float = 0.01, max_level: int = 18,
               snap_z: Sequence[float] = (), h_max: Optional[float] = None, jitter: float = 0.12,
-              improve_passes: int = 6) -> Mesh:
+              improve_passes: int = 6, interfaces: Sequence[np.ndarray] = ()) -> Mesh:
     """Graded Delaunay mesh of the reference's half disc (dim=2) or half ball (dim=3).
 
     sources_z : axis positions of current electrodes (refinement centres, snapped to vertices)
@@ -166,6 +166,9 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     h_max     : cap on the size field (default R/5; keeps the polyhedral outer boundary round)
     jitter    : seeded displacement of interior lattice points, fraction of the local cell size
     improve_passes : sliver-removal passes (3D): perturb vertices of elements with quality < 0.15, re-triangulate
+    interfaces : (2D only) polylines [(r, z), ...] that must be unions of mesh edges (material
+                 interfaces).  They are sampled at ~0.6 h and lattice points closer than 0.8 of that
+                 spacing are removed, which makes every sub-segment a Gabriel - hence Delaunay - edge.
     """
     from scipy.spatial import Delaunay, cKDTree
 
@@ -197,6 +200,57 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     dd, ii = tree.query(pts, k=2)
     dup = (dd[:, 1] < 0.3 * np.minimum(hs, hs[ii[:, 1]])) & (ii[:, 1] < np.arange(len(pts))) & proj
     pts, hs, proj, on_axis = pts[~dup], hs[~dup], proj[~dup], on_axis[~dup]
+
+    # conforming interfaces (2D): sample the polylines, clear a corridor around them
+    n_iface = 0
+    if dim == 2 and len(interfaces):
+        ip, isp = [], []
+        for poly in interfaces:
+            poly = np.asarray(poly, dtype=np.float64)
+            for a, b in zip(poly[:-1], poly[1:]):
+                ra, rb_ = np.hypot(*a), np.hypot(*b)
+                if ra >= R and rb_ >= R:
+                    continue
+                if ra > R or rb_ > R:   # clip the segment at the outer circle
+                    (pin, pout) = (a, b) if ra < R else (b, a)
+                    d = pout - pin
+                    A_, B_, C_ = d @ d, 2 * (pin @ d), pin @ pin - R * R
+                    t = (-B_ + np.sqrt(B_ * B_ - 4 * A_ * C_)) / (2 * A_)
+                    hit = pin + t * d
+                    hit *= R / np.hypot(*hit)
+                    a, b = (pin, hit)
+                L = np.hypot(*(b - a))
+                if L == 0:
+                    continue
+                pos = 0.0
+                while pos < L:
+                    q = a + (pos / L) * (b - a)
+                    hq = 0.6 * float(np.minimum(size_field(q[None, :], 2, sources_z, scale, h_axis, h_src), h_max)[0])
+                    ip.append(q); isp.append(min(hq, L))
+                    pos += hq
+                    if L - pos < 0.5 * hq:      # avoid a short last piece: the end point closes the segment
+                        break
+                ip.append(b.copy()); isp.append(isp[-1])
+        ip = np.array(ip); isp = np.array(isp)
+        # merge coincident / very close interface points (junctions are listed by both polylines)
+        keep_i = np.ones(len(ip), bool)
+        ti = cKDTree(ip)
+        for i, j in ti.query_pairs(1e-9 + 0.0):
+            keep_i[max(i, j)] = False
+        for i, j in sorted(ti.query_pairs(float(isp.max()))):
+            if keep_i[i] and keep_i[j] and np.hypot(*(ip[i] - ip[j])) < 0.3 * min(isp[i], isp[j]):
+                # keep polyline vertices / junctions in preference to marching points: drop the later one
+                keep_i[j] = False
+        ip, isp = ip[keep_i], isp[keep_i]
+        ti = cKDTree(ip)
+        dnn, inn = ti.query(pts)
+        clear = (dnn < 0.8 * isp[inn]) & (~on_axis)
+        pts, hs, proj, on_axis = pts[~clear], hs[~clear], proj[~clear], on_axis[~clear]
+        n_iface = len(ip)
+        iface_on_rim = np.hypot(ip[:, 0], ip[:, 1]) >= R * (1 - 1e-12)
+        pts = np.concatenate([pts, ip]); hs = np.concatenate([hs, isp])
+        proj = np.concatenate([proj, np.ones(n_iface, bool)])          # interface points are pinned like boundary points
+        on_axis = np.concatenate([on_axis, ip[:, 0] == 0.0])
 
     # jitter strictly interior, off-plane points to break lattice degeneracies (seeded)
     on_plane = np.zeros(len(pts), bool) if dim == 2 else (pts[:, 1] == 0.0)
@@ -293,7 +347,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     exact = (np.pi * R * R / 2) if dim == 2 else (2.0 / 3.0 * np.pi * R ** 3)
     meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z],
                 volume=float(vol.sum()), volume_exact=float(exact), min_quality=float(qual.min()),
-                max_valence=int(valence))
+                max_valence=int(valence), n_interface_points=int(n_iface))
     return Mesh(dim, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)),
                 np.ascontiguousarray(mat), np.ascontiguousarray(bf.astype(np.int32)),
                 np.ascontiguousarray(bdir.astype(np.uint8)), meta)
@@ -340,3 +394,38 @@ def layered_material_fn(dim: int, local_formation_geometry: np.ndarray, local_bo
         return m
 
     return fn
+
+
+def layer_interfaces_2d(local_formation_geometry: np.ndarray, local_borehole_geometry: np.ndarray, R: float):
+    """Material interfaces of a windowed axisymmetric model as polylines of (r, z) points: the
+    borehole wall, the layer boundaries outside the borehole and the flushed-zone radii - the curves
+    the reference hands to its mesher as geometry (gmsh_functions.py:404-480, netgen_functions.py:129-311).
+    Junction points are shared between the polylines that meet there."""
+    fg = np.asarray(local_formation_geometry, dtype=np.float64)
+    bg = np.asarray(local_borehole_geometry, dtype=np.float64)
+    rb = lambda z: float(np.interp(z, bg[:, 0], bg[:, 1]))
+    bounds = [float(fg[i, 1]) for i in range(fg.shape[0] - 1) if abs(fg[i, 1]) < R]
+    # borehole wall with the junctions of the layer boundaries inserted
+    zs = sorted(set(list(bg[:, 0]) + [b for b in bounds if bg[0, 0] < b < bg[-1, 0]]))
+    wall = np.array([[rb(z), z] for z in zs])
+    polys = [wall]
+    for i, b in enumerate(bounds):
+        r0, r1 = rb(b), float(np.sqrt(max(R * R - b * b, 0.0)))
+        if r1 <= r0:
+            continue
+        stops = [r0, r1]
+        for layer in (i, i + 1):                       # flushed-zone radii ending on this boundary
+            fz = fg[layer, 2]
+            if not np.isnan(fz) and r0 < fz < r1:
+                stops.append(float(fz))
+        stops = sorted(set(stops))
+        polys.append(np.array([[r, b] for r in stops]))
+    for i in range(fg.shape[0]):
+        fz = fg[i, 2]
+        if np.isnan(fz) or fz >= R:
+            continue
+        zlim = float(np.sqrt(R * R - fz * fz))
+        z0, z1 = max(float(fg[i, 0]), -zlim), min(float(fg[i, 1]), zlim)
+        if z1 > z0:
+            polys.append(np.array([[fz, z0], [fz, z1]]))
+    return polys

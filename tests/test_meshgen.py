@@ -49,3 +49,42 @@ def test_layered_material_classifier_orders_zones_like_the_reference():
     fn30 = meshgen.layered_material_fn(3, fg, bh, dip_rad=np.deg2rad(30))
     assert fn30(np.array([[2.0, 0.0, 0.5]])).tolist() == [3]      # 0.5 + tan30*2 = 1.65 > 1 -> lower layer, outside fz
     assert fn30(np.array([[-2.0, 0.0, 1.5]])).tolist() == [1]     # 1.5 - 1.15 = 0.35 < 1 -> upper layer
+
+
+def test_conforming_2d_mesh_keeps_interfaces_as_edges():
+    """Every sampled piece of the borehole wall, of the layer boundaries and of the flushed-zone radii
+    is a mesh edge, so no element straddles a material interface."""
+    R = 50.0
+    fg = np.array([[-60.0, -1.0, np.nan], [-1.0, 2.5, 0.4], [2.5, 60.0, np.nan]])
+    bh = np.array([[-50.0, 0.11], [-2.0, 0.12], [0.0, 0.13], [3.0, 0.10], [50.0, 0.11]])
+    bh[0, 0] = -np.sqrt(R * R - bh[0, 1] ** 2); bh[-1, 0] = np.sqrt(R * R - bh[-1, 1] ** 2)
+    polys = meshgen.layer_interfaces_2d(fg, bh, R)
+    fn = meshgen.layered_material_fn(2, fg, bh)
+    m = meshgen.make_mesh(2, R, [0.0, 0.2], scale=1.0, interfaces=polys, material_fn=fn)
+    assert m.meta["n_interface_points"] > 100 and m.meta["min_quality"] > 0.15
+    X = m.coords
+    edges = set()
+    for t in m.conn:
+        for a, b in ((0, 1), (0, 2), (1, 2)):
+            edges.add((min(t[a], t[b]), max(t[a], t[b])))
+    # points of the mesh that lie on each polyline, ordered along it, must be chained by edges
+    from scipy.spatial import cKDTree
+    missing = total = 0
+    for poly in polys:
+        for a, b in zip(poly[:-1], poly[1:]):
+            d = b - a
+            L = np.hypot(*d)
+            if np.hypot(*a) > R or np.hypot(*b) > R * (1 + 1e-9):
+                continue
+            t = ((X - a) @ d) / (L * L)
+            dist = np.abs((X[:, 0] - a[0]) * d[1] - (X[:, 1] - a[1]) * d[0]) / L
+            on = np.nonzero((dist < 1e-9) & (t > -1e-9) & (t < 1 + 1e-9))[0]
+            on = on[np.argsort(t[on])]
+            for i, j in zip(on[:-1], on[1:]):
+                total += 1
+                missing += (min(i, j), max(i, j)) not in edges
+    assert total > 100 and missing == 0, (missing, total)
+    # consequently the two elements at an interface edge carry different materials and no element mixes them
+    c = X[m.conn].mean(1)
+    assert np.array_equal(fn(c), m.mat)
+    assert set(np.unique(m.mat)) == {0, 1, 2, 3, 4}

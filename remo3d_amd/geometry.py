@@ -133,3 +133,92 @@ def select_data_range(borehole_geometry, formation_parameters, dip, mud_resistiv
     fg, res = window_formation(formation_parameters, dip, depth, R, active_geometry_window)
     sigma = [1.0 / mud_resistivity] + list(1.0 / res)
     return fg, bh, sigma
+
+
+# ---------------------------------------------------------------------------------------------
+# Netgen path (2D only): remo3d/netgen_functions.py:12-118
+
+
+def _segment_circle_hit_side(p1, p2, radius, side):
+    """Like _segment_circle_hit, restricted to the upper (z < 0) or lower (z > 0) half
+    (netgen_functions.py:14-29)."""
+    x1, y1 = p1[1], p1[0]
+    x2, y2 = p2[1], p2[0]
+    dx, dy = x2 - x1, y2 - y1
+    dr2 = dx * dx + dy * dy
+    D = x1 * y2 - x2 * y1
+    disc = radius ** 2 * dr2 - D ** 2
+    for sign in (-1, 1):
+        x = (D * dy + sign * np.sign(dy) * dx * np.sqrt(disc)) / dr2
+        y = (-D * dx + sign * np.abs(dy) * np.sqrt(disc)) / dr2
+        p = np.array([y, x])
+        t = np.dot(p1 - p2, p1 - p)
+        if ((side == "top" and y < 0) or (side == "bottom" and y > 0)) and 0 < t < np.dot(p1 - p2, p1 - p2):
+            return p
+    return None
+
+
+def select_netgen_data_range(borehole_geometry, formation_parameters, mud_resistivity, depth, R, active_geometry_window=0.999):
+    """Windowing of the reference's default 2D path (mesh_generator "netgen", remo3d.py:776-779):
+    returns (local_formation_geometry [L, 5] = top, bottom, fz_radius, region numbers left / right,
+    local_borehole_geometry [B, 2], sigma).  Quirks kept because they define the reference's inputs:
+    the position of the borehole end points relative to the domain is tested with z^2 + r (radius NOT
+    squared, netgen_functions.py:43-62); the active radius is 0.999 R; a flushed zone is dropped only if
+    both inner corners AND the connecting line lie outside the active radius; the first / last layer is
+    cut at the borehole polyline's end points instead of being stretched."""
+    bg = np.asarray(borehole_geometry, dtype=float)
+    fp = np.asarray(formation_parameters, dtype=float)
+    if bg.shape[0] == 2:
+        loc = bg.copy()
+    else:
+        inside = (bg[:, 0] - depth) ** 2 + bg[:, 1] ** 2 < R ** 2
+        grown = inside.copy()
+        grown[:-1] |= inside[1:]
+        grown[1:] |= inside[:-1]
+        loc = bg[grown, :].copy()
+    loc[:, 0] -= depth
+    for end, side in ((0, "top"), (-1, "bottom")):
+        nxt = 1 if end == 0 else -2
+        sgn = -1.0 if end == 0 else 1.0
+        q = loc[end, 0] ** 2 + loc[end, 1]          # sic: radius not squared
+        if np.isclose(q, R ** 2):
+            continue
+        if q < R ** 2:
+            omega = np.arccos(loc[end, 1] / R)
+            new = np.array([sgn * np.sin(omega) * R, loc[end, 1]])
+            loc = np.vstack((new, loc)) if end == 0 else np.vstack((loc, new))
+        else:
+            loc[end, :] = _segment_circle_hit_side(loc[end, :], loc[nxt, :], R, side)
+
+    active = R * active_geometry_window
+    rel = fp[:, :2] - depth
+    point_within = np.any(rel ** 2 <= active ** 2, axis=1)
+    line_across = np.all(rel ** 2 > active ** 2, axis=1) & (fp[:, 0] < depth) & (fp[:, 1] > depth)
+    model = fp[point_within | line_across, :].copy()
+    model[:, :2] -= depth
+    has_fz = ~np.isnan(model[:, 2])
+    top_out = model[:, 0] ** 2 + model[:, 2] ** 2 >= active ** 2
+    bot_out = model[:, 1] ** 2 + model[:, 2] ** 2 >= active ** 2
+    line_out = ~((model[:, 0] < 0) & (model[:, 1] > 0) & (model[:, 2] < active))
+    drop = has_fz & top_out & bot_out & line_out
+    model[drop, 2] = np.nan
+    model[drop, 4] = model[drop, 3]
+    model[drop, 3] = np.nan
+    if model[0, 0] != loc[0, 0]:
+        model[0, 0] = loc[0, 0]
+    if model[-1, 1] != loc[-1, 0]:
+        model[-1, 1] = loc[-1, 0]
+    grid = np.empty((model.shape[0], 2))
+    region = 2
+    for i in range(model.shape[0]):
+        if np.isnan(model[i, 3]):
+            grid[i, :] = region
+            region += 1
+        else:
+            grid[i, 0] = region
+            grid[i, 1] = region + 1
+            region += 2
+    res = model[:, 3:5].ravel()
+    res = res[~np.isnan(res)]
+    sigma = [1.0 / mud_resistivity] + list(1.0 / res)
+    return np.hstack((model[:, :3], grid)), loc, sigma

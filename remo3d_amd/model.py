@@ -236,6 +236,7 @@ class Model:
         if self.dip_deg != 0:
             self.borehole_model = self._add_points_to_borehole()
         dim = 3 if is3d else 2
+        netgen_path = (not is3d) and mesh_generator in ("auto", "netgen")
         provider = mesh_provider or default_mesh_provider(scale=mesh_scale)
 
         simulation_depths, batches = self._prepare_simulation_depths_and_tasks(measurement_depths, batch_size)
@@ -254,8 +255,12 @@ class Model:
             rows = [(r.depth_index, r.tool_index) for s in batch.solves for r in s.records]
             try:
                 t0 = time.time()
-                fg, bh, sigma = geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0,
-                                                           mud[bi], simulation_depths[bi], domain_radius)
+                if netgen_path:   # the reference's default 2D windowing (remo3d.py:776-779, worker.py:94)
+                    fg, bh, sigma = geometry.select_netgen_data_range(borehole_geometry, self.formation_model, mud[bi],
+                                                                      simulation_depths[bi], domain_radius)
+                else:             # Gmsh-path windowing (worker.py:84), the only one for dipping models
+                    fg, bh, sigma = geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0,
+                                                               mud[bi], simulation_depths[bi], domain_radius)
                 mesh = provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
                 sources, evals, readers = tasks.batch_rhs(batch, self.tools)
                 t1 = time.time()

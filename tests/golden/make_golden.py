@@ -121,3 +121,29 @@ dump("windows_bm3_30.json", window_case(os.path.join(bm, "Benchmark model 3/Form
                                         30, np.array([2.75, 5.0, 12.5, 19.8]), 50.0, tool_sets["bm3"]))
 dump("windows_bm3_60_r6.json", window_case(os.path.join(bm, "Benchmark model 3/Formation_BM3_60.txt"), os.path.join(bm, "Benchmark model 3/Borehole_BM3.txt"),
                                            60, np.array([2.75, 9.0, 12.5, 19.8]), 6.0, tool_sets["bm3"]))
+
+
+# ---- Netgen-path windowing (2D default of the reference) -----------------------------------------
+import netgen_functions as ref_ngf  # noqa: E402
+
+
+def netgen_window_case(formation, borehole, depths, R, names):
+    m = ref_main.Model(names)
+    m.set_model_parameters(formation, borehole, dip=0)
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    mud = np.interp(depths, m.borehole_model[:, 0], m.borehole_model[:, 2])
+    cases = []
+    for d, rm in zip(depths, mud):
+        fg, bh, sigma = ref_ngf.SelectNetgenDataRange(bg.copy(), m.formation_model.copy(), rm, d, R)
+        cases.append(dict(depth=float(d), rm=float(rm), formation_geometry=fg.tolist(), borehole_geometry=bh.tolist(), sigma=[float(s) for s in sigma]))
+    return dict(formation_file=os.path.relpath(formation, EX), borehole_file=os.path.relpath(borehole, EX), R=R, cases=cases)
+
+
+dump("netgen_windows_example_01.json", netgen_window_case(os.path.join(EX, "Example_01/Input/Formation.txt"), os.path.join(EX, "Example_01/Input/Borehole.txt"),
+                                                          np.array([0.5, 3.0, 8.3, 12.45, 20.0, 24.9]), 50.0, tool_sets["bm3"]))
+dump("netgen_windows_example_01_r5.json", netgen_window_case(os.path.join(EX, "Example_01/Input/Formation.txt"), os.path.join(EX, "Example_01/Input/Borehole.txt"),
+                                                             np.array([0.5, 3.0, 8.3, 12.45, 20.0, 24.9]), 5.0, tool_sets["bm3"]))
+dump("netgen_windows_bm2.json", netgen_window_case(os.path.join(bm, "Benchmark model 2/Formation_BM2.txt"), os.path.join(bm, "Benchmark model 2/Borehole_BM2.txt"),
+                                                   np.array([4.8, 15.0, 30.1, 55.0]), 50.0, tool_sets["bm3"]))
+dump("netgen_windows_bm2_r8.json", netgen_window_case(os.path.join(bm, "Benchmark model 2/Formation_BM2.txt"), os.path.join(bm, "Benchmark model 2/Borehole_BM2.txt"),
+                                                      np.array([4.8, 15.0, 30.1, 55.0]), 8.0, tool_sets["bm3"]))

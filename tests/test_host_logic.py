@@ -126,3 +126,17 @@ def test_results_writer_layout(tmp_path):
     lines = open(files[0]).read().splitlines()
     assert lines[0] == "DEPTH\tA0.4M6.0N\tA2.0M0.5N" and lines[1] == "M\tOHMM\tOHMM"
     assert lines[3] == "1.1000\t5.1235\t8.0000" and lines[4].endswith("nan")
+
+
+@pytest.mark.parametrize("fixture", ["netgen_windows_example_01.json", "netgen_windows_example_01_r5.json", "netgen_windows_bm2.json",
+                                     "netgen_windows_bm2_r8.json"])
+def test_netgen_path_windowing_matches_reference(fixture, examples_dir):
+    gold = load(fixture)
+    m = Model(["A0.4M6.0N", "A2.0M0.5N"])
+    m.set_model_parameters(os.path.join(examples_dir, gold["formation_file"]), os.path.join(examples_dir, gold["borehole_file"]))
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    for case in gold["cases"]:
+        fg, bh, sigma = geometry.select_netgen_data_range(bg, m.formation_model, case["rm"], case["depth"], gold["R"])
+        np.testing.assert_allclose(fg, np.array(case["formation_geometry"], dtype=float), rtol=1e-13, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(bh, np.array(case["borehole_geometry"]), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(sigma, case["sigma"], rtol=1e-13)

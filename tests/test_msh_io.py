@@ -1,0 +1,88 @@
+"""MSH 2.2 ingress with the reference's numbering conventions (gmsh_functions.py:177-382)."""
+import numpy as np
+import pytest
+
+from remo3d_amd import msh_io
+
+SMALL = """$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$PhysicalNames
+4
+1 1 "dirichlet_boundary"
+1 2 "neumann_boundary"
+2 7 "surf_1"
+2 9 "surf_2"
+$EndPhysicalNames
+$Nodes
+5
+10 0 0 0
+20 1 0 0
+30 1 1 0
+40 0 1 0
+50 0.5 0.5 0
+$EndNodes
+$Elements
+9
+1 15 2 0 1 10
+2 1 2 2 11 10 20
+3 1 2 1 12 20 30
+4 1 2 1 13 30 40
+5 1 2 2 14 40 10
+6 2 2 9 9 10 20 50
+7 2 2 7 7 20 30 50
+8 2 2 7 7 30 40 50
+9 2 2 9 9 40 10 50
+$EndElements
+"""
+
+
+def test_reads_reference_conventions(tmp_path):
+    p = tmp_path / "fm_0.msh"
+    p.write_text(SMALL)
+    m = msh_io.read_msh(str(p), 2)
+    assert m.n_nodes == 5 and m.n_elems == 4 and m.coords.shape == (5, 2)
+    # material numbers follow FIRST APPEARANCE of the elementary tag (9 first, then 7), not tag order
+    assert m.mat.tolist() == [0, 1, 1, 0]
+    assert m.conn.tolist() == [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]        # node ids remapped to 0-based positions
+    assert m.bconn.tolist() == [[0, 1], [1, 2], [2, 3], [3, 0]]
+    assert m.bdirichlet.tolist() == [0, 1, 1, 0]                                   # by physical NAME
+    with pytest.raises(ValueError):
+        msh_io.read_msh(str(p), 3)                                                 # no tetrahedra in the file
+
+
+@pytest.mark.parametrize("which", ["2d", "3d"])
+def test_write_read_round_trip(which, mesh2d, mesh3d, tmp_path):
+    mesh = mesh2d if which == "2d" else mesh3d
+    p = str(tmp_path / "m.msh")
+    msh_io.write_msh(p, mesh)
+    back = msh_io.read_msh(p, mesh.dim)
+    assert np.array_equal(back.coords, mesh.coords)            # %.17g round-trips doubles
+    # the writer emits elements entity by entity, so compare as sets keyed by connectivity
+    a = {tuple(c): int(t) for c, t in zip(mesh.conn.tolist(), mesh.mat.tolist())}
+    b = {tuple(c): int(t) for c, t in zip(back.conn.tolist(), back.mat.tolist())}
+    assert a.keys() == b.keys()
+    # materials are renumbered by first appearance: the map old -> new must be a bijection
+    pairs = {(a[k], b[k]) for k in a}
+    assert len(pairs) == len({x for x, _ in pairs}) == len({y for _, y in pairs})
+    assert sorted(map(tuple, back.bconn.tolist())) == sorted(map(tuple, mesh.bconn.tolist()))
+    assert int(back.bdirichlet.sum()) == int(mesh.bdirichlet.sum())
+
+
+def test_round_trip_preserves_the_linear_system(mesh2d, tmp_path):
+    """Reading a mesh back gives the same physical problem: oracle potentials agree to rounding."""
+    from oracle.fem_oracle import solve_batch
+    from conftest import SIGMA3
+    p = str(tmp_path / "m.msh")
+    msh_io.write_msh(p, mesh2d)
+    back = msh_io.read_msh(p, 2)
+    # sigma follows the material renumbering of the file
+    old_of_new = {}
+    a = {tuple(c): int(t) for c, t in zip(mesh2d.conn.tolist(), mesh2d.mat.tolist())}
+    for c, t in zip(back.conn.tolist(), back.mat.tolist()):
+        old_of_new[int(t)] = a[tuple(c)]
+    sigma_back = [SIGMA3[old_of_new[k]] for k in range(len(old_of_new))]
+    args = ([0, 1], [0.0], [1.0], [0, 2], [0.4, 6.4])
+    u0, rc0, _ = solve_batch(mesh2d, SIGMA3, *args, rtol=1e-12)
+    u1, rc1, _ = solve_batch(back, sigma_back, *args, rtol=1e-12)
+    assert rc0 == 0 and rc1 == 0 and np.allclose(u0, u1, rtol=1e-9)

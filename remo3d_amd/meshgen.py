@@ -205,42 +205,50 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     n_iface = 0
     if dim == 2 and len(interfaces):
         ip, isp = [], []
+        src_list = [float(v) for v in sources_z]
+        import math
+
+        def h_at(r_, z_):                    # scalar copy of size_field (these loops are hot: pure Python floats)
+            rho = abs(r_)
+            hq = rho + h_axis
+            for zs in src_list:
+                hq = min(hq, 0.5 * (rho * rho + (z_ - zs) ** 2) + h_src)
+            return 0.6 * min(scale * hq, h_max)
+
         for poly in interfaces:
-            poly = np.asarray(poly, dtype=np.float64)
-            for a, b in zip(poly[:-1], poly[1:]):
-                ra, rb_ = np.hypot(*a), np.hypot(*b)
+            pl = [(float(p_[0]), float(p_[1])) for p_ in np.asarray(poly, dtype=np.float64)]
+            for (ar, az), (br, bz) in zip(pl[:-1], pl[1:]):
+                ra, rb_ = math.hypot(ar, az), math.hypot(br, bz)
                 if ra >= R and rb_ >= R:
                     continue
                 if ra > R or rb_ > R:   # clip the segment at the outer circle
-                    (pin, pout) = (a, b) if ra < R else (b, a)
-                    d = pout - pin
-                    A_, B_, C_ = d @ d, 2 * (pin @ d), pin @ pin - R * R
-                    t = (-B_ + np.sqrt(B_ * B_ - 4 * A_ * C_)) / (2 * A_)
-                    hit = pin + t * d
-                    hit *= R / np.hypot(*hit)
-                    a, b = (pin, hit)
-                L = np.hypot(*(b - a))
+                    (pr_, pz_), (qr_, qz_) = ((ar, az), (br, bz)) if ra < R else ((br, bz), (ar, az))
+                    dr_, dz_ = qr_ - pr_, qz_ - pz_
+                    A_, B_, C_ = dr_ * dr_ + dz_ * dz_, 2 * (pr_ * dr_ + pz_ * dz_), pr_ * pr_ + pz_ * pz_ - R * R
+                    t = (-B_ + math.sqrt(B_ * B_ - 4 * A_ * C_)) / (2 * A_)
+                    hr_, hz_ = pr_ + t * dr_, pz_ + t * dz_
+                    sc_ = R / math.hypot(hr_, hz_)
+                    (ar, az), (br, bz) = (pr_, pz_), (hr_ * sc_, hz_ * sc_)
+                L = math.hypot(br - ar, bz - az)
                 if L == 0:
                     continue
                 pos = 0.0
+                hq = L
                 while pos < L:
-                    q = a + (pos / L) * (b - a)
-                    hq = 0.6 * float(np.minimum(size_field(q[None, :], 2, sources_z, scale, h_axis, h_src), h_max)[0])
-                    ip.append(q); isp.append(min(hq, L))
+                    qr_, qz_ = ar + (pos / L) * (br - ar), az + (pos / L) * (bz - az)
+                    hq = h_at(qr_, qz_)
+                    ip.append((qr_, qz_)); isp.append(min(hq, L))
                     pos += hq
                     if L - pos < 0.5 * hq:      # avoid a short last piece: the end point closes the segment
                         break
-                ip.append(b.copy()); isp.append(isp[-1])
-        ip = np.array(ip); isp = np.array(isp)
-        # merge coincident / very close interface points (junctions are listed by both polylines)
-        keep_i = np.ones(len(ip), bool)
+                ip.append((br, bz)); isp.append(min(hq, L))
+        ip = np.array(ip, dtype=np.float64); isp = np.array(isp)
+        # merge coincident / very close interface points (junctions are listed by both polylines):
+        # of two points closer than 0.3 of their spacing the later one goes
         ti = cKDTree(ip)
-        for i, j in ti.query_pairs(1e-9 + 0.0):
-            keep_i[max(i, j)] = False
-        for i, j in sorted(ti.query_pairs(float(isp.max()))):
-            if keep_i[i] and keep_i[j] and np.hypot(*(ip[i] - ip[j])) < 0.3 * min(isp[i], isp[j]):
-                # keep polyline vertices / junctions in preference to marching points: drop the later one
-                keep_i[j] = False
+        dd2, ii2 = ti.query(ip, k=2)
+        close = dd2[:, 1] < 0.3 * np.minimum(isp, isp[ii2[:, 1]])
+        keep_i = ~(close & (np.arange(len(ip)) > ii2[:, 1]))
         ip, isp = ip[keep_i], isp[keep_i]
         ti = cKDTree(ip)
         dnn, inn = ti.query(pts)

@@ -143,6 +143,7 @@ def main():
                 for (di, ti, K, o, m) in rd:
                     slab[di, ti] = tasks.apparent_resistivity(u[o:o + m], m, K, 3)
             agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
+            agg["spmv_ms_raw"] = agg.get("spmv_ms_raw", 0.0) + st["spmv_ms_raw"]; agg["ev_over"] = st["event_overhead_ms"]
             agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
             agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
             for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
@@ -177,6 +178,8 @@ def main():
                                         int(agg["n"]), int(agg["nnz"])),
                     kernel="k_spmm (CSR SpMM, fp64, k=5 interleaved RHS)", launches=int(agg["spmv_launches"]),
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+                    avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+                    empty_event_pair_us=1e3 * agg.get("ev_over", 0.0),
                     bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)", traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_b_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,

@@ -81,10 +81,14 @@ typedef struct {
     double ms_solve;     /* PCG, all RHS (device, HIP events)                                      */
     double ms_eval;      /* point location + RHS build + evaluation                                */
     double ms_total;     /* wall clock of the call                                                 */
-    double spmv_ms;      /* sum of event-timed SpMV launches (time_kernels = 1)                    */
+    double spmv_ms;      /* sum of event-timed SpMV launches (time_kernels = 1), minus the bracket
+                            overhead below per launch                                             */
     int64_t spmv_launches;
     double spmv_bytes;   /* algorithmic bytes of ONE SpMV launch: 12 nnz + 4 n + 16 k n            */
     int64_t pcg_steps;   /* total PCG steps executed on the device (incl. post-convergence slack)  */
+    double spmv_ms_raw;  /* the same sum before the correction                                     */
+    double event_overhead_ms; /* elapsed time of an EMPTY hipEvent pair on the stream (min of 16),
+                            i.e. what a bracket measures beyond the kernel it encloses             */
 } remo_stats_t;
 
 typedef struct remo_ctx remo_ctx_t;

@@ -34,7 +34,7 @@ class RemoStats(C.Structure):
                 ("ms_symbolic", C.c_double), ("ms_h2d", C.c_double), ("ms_assemble", C.c_double),
                 ("ms_solve", C.c_double), ("ms_eval", C.c_double), ("ms_total", C.c_double),
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_double),
-                ("pcg_steps", C.c_int64)]
+                ("pcg_steps", C.c_int64), ("spmv_ms_raw", C.c_double), ("event_overhead_ms", C.c_double)]
 
     def as_dict(self):
         d = {}

@@ -319,13 +319,29 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
     double dot[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) dot[c] = 0.0;
-    for (int64_t g = int64_t(blockIdx.x) * rpb + grp; g < ngroups; g += int64_t(gridDim.x) * rpb) {
-        int64_t row;
-        bool pair = false;
-        if (g < pair_begin) row = g;
-        else if (g < pair_begin + npair) { row = pair_begin + 2 * (g - pair_begin); pair = true; }
-        else row = g + npair;
-        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+    // row of lane-group index g (edge rows are taken two at a time)
+    auto row_of = [&](int64_t g, bool &pair) -> int64_t {
+        pair = false;
+        if (g < pair_begin) return g;
+        if (g < pair_begin + npair) { pair = true; return pair_begin + 2 * (g - pair_begin); }
+        return g + npair;
+    };
+    const int64_t gstep = int64_t(gridDim.x) * rpb;
+    int64_t g = int64_t(blockIdx.x) * rpb + grp;
+    bool pair_n = false;
+    int64_t row_n = (g < ngroups) ? row_of(g, pair_n) : 0;
+    int32_t rs_n = (g < ngroups) ? rowptr[row_n] : 0, re_n = (g < ngroups) ? rowptr[row_n + 1] : 0;
+    for (; g < ngroups; g += gstep) {
+        const int64_t row = row_n;
+        const bool pair = pair_n;
+        const int32_t rs = rs_n, re = re_n;
+        // the row pointers of the NEXT row are requested now: one of the three dependent round trips
+        // of a row (pointers -> indices -> x) leaves the critical path
+        if (g + gstep < ngroups) {
+            row_n = row_of(g + gstep, pair_n);
+            rs_n = rowptr[row_n];
+            re_n = rowptr[row_n + 1];
+        }
         const int32_t len = pair ? re - rs : 0;   // the second row's values sit `len` entries further
         double acc0[K], acc1[K];
 #pragma unroll
@@ -336,18 +352,22 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int32_t p = p0 + u * LPR;
-                const bool ok = p < re;
-                const int32_t ps = ok ? p : rs;      // in-range address for idle lanes
-                j[u] = col[ps];
-                const double a = val[ps], b = val[ps + len];
-                v0[u] = ok ? a : 0.0;
-                v1[u] = ok ? b : 0.0;
+                j[u] = -1; v0[u] = 0.0; v1[u] = 0.0;
+                if (p < re) {                        // lanes past the row end issue nothing (exec-masked loads)
+                    j[u] = col[p];
+                    v0[u] = val[p];
+                    v1[u] = val[p + len];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double *xr = x + int64_t(j[u]) * K;
 #pragma unroll
-                for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+                for (int c = 0; c < K; ++c) xv[u][c] = 0.0;
+                if (j[u] >= 0) {
+                    const double *xr = x + int64_t(j[u]) * K;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)

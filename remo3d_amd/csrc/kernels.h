@@ -21,7 +21,7 @@ struct PcgBuffers {
     const double *dinv;     // [n]
     double *part_pq;        // [kMaxPartialBlocks*8] per-workgroup partial sums of <p, Ap>
     double *part_rz;        // [2][kMaxPartialBlocks*8] per-workgroup partial sums of <Cr, r> (even / odd step)
-    double *rz0;            // [8] device copy of <Cr0,r0>
+    double *rz0;            // [32] totals forwarded between launches: <Cr0,r0>[8] | <p,Ap>[8] | <Cr,r> of even / odd steps [8+8]
     // two-level preconditioner (vertex-block Chebyshev); cheb_degree = 0 -> Jacobi
     int64_t nv_coarse;      // free vertex dofs = size of the leading P1 block
     int cheb_degree;

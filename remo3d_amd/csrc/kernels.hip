@@ -642,9 +642,18 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     PcgProgress *progress, int progress_len, const double *__restrict__ p,
                                                     const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
                                                     const double *__restrict__ dinv) {
+    // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
+    // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
+    double *scal = rz0;
     double pq[K], rz[K], unused[K], alpha[K], acc[K];
-    reduce_partials3<K>(part_pq, nb_spmv, part_rz_cur, nb_rz, nullptr, 0, pq, rz, unused, smem);
+    if (step == 0) {
+        reduce_partials3<K>(part_pq, nb_spmv, part_rz_cur, nb_rz, nullptr, 0, pq, rz, unused, smem);
+    } else {
+        reduce_partials<K>(part_pq, nb_spmv, pq, smem);
+#pragma unroll
+        for (int c = 0; c < K; ++c) rz[c] = scal[16 + 8 * (step & 1) + c];
+    }
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         const double r0 = (step == 0) ? rz[c] : rz0[c];
@@ -653,9 +662,11 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         acc[c] = 0.0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) scal[8 + c] = pq[c];
         if (step == 0)
 #pragma unroll
-            for (int c = 0; c < K; ++c) rz0[c] = rz[c];
+            for (int c = 0; c < K; ++c) { rz0[c] = rz[c]; scal[16 + c] = rz[c]; }
         // progress record in mapped host memory: data first, then the step number (system scope)
         PcgProgress *pr = progress + (step % progress_len);
 #pragma unroll
@@ -735,24 +746,27 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, double tol2, int nb_spmv, int nb_rz, ChebArgs ch,
-                                                       const double *__restrict__ part_pq, const double *__restrict__ part_rz_old,
-                                                       const double *__restrict__ part_rz_new, const double *__restrict__ rz0,
+__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgs ch,
+                                                       const double *__restrict__ part_rz_new, double *__restrict__ scal,
                                                        const double *__restrict__ r, double *__restrict__ p,
                                                        const double *__restrict__ dinv) {
-    __shared__ double smem[16 * 3 * K];
+    __shared__ double smem[16 * K];
     double beta[K];
     if (first) {  // p0 = C r0
 #pragma unroll
         for (int c = 0; c < K; ++c) beta[c] = 0.0;
     } else {
-        double pq[K], rzo[K], rzn[K];
-        reduce_partials3<K>(part_pq, nb_spmv, part_rz_old, nb_rz, part_rz_new, nb_rz, pq, rzo, rzn, smem);
+        double rzn[K];
+        reduce_partials<K>(part_rz_new, nb_rz, rzn, smem);
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            const bool live = (rzo[c] > tol2 * rz0[c]) && (pq[c] > 0.0);
-            beta[c] = live ? rzn[c] / rzo[c] : 0.0;
+            const double pq = scal[8 + c], rzo = scal[16 + 8 * (step & 1) + c];   // forwarded by the update launch
+            const bool live = (rzo > tol2 * scal[c]) && (pq > 0.0);
+            beta[c] = live ? rzn[c] / rzo : 0.0;
         }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+#pragma unroll
+            for (int c = 0; c < K; ++c) scal[16 + 8 * ((step + 1) & 1) + c] = rzn[c];   // read by the next update launch
     }
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const double d = dinv[i];
@@ -874,8 +888,7 @@ void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers 
     REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_init<KK>, dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
     launch_cheb(A, k, b, b.part_rz, s);
     if (ch.nv > 0)
-        REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 1, 0.0, b.nb_spmv, nb_rz(b), ch, b.part_pq, b.part_rz,
-                                            b.part_rz, b.rz0, b.r, b.p, b.dinv));
+        REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv));
 }
 
 void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
@@ -892,11 +905,9 @@ void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const Pcg
 void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
-    const double *old = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgs ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 0, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, old, nw, b.rz0,
-                                        b.r, b.p, b.dinv));
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv));
 }
 
 void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s) {

@@ -405,7 +405,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.dinv = d_dinv;
         buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
         buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
-        buf.rz0 = ctx->take<double>(8);
+        buf.rz0 = ctx->take<double>(32);
         const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
         buf.nv_coarse = two_level ? sy.nvfree : 0;
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : 6) : 0;

@@ -66,7 +66,43 @@ def size_field(pts: np.ndarray, dim: int, sources_z: Sequence[float], scale: flo
     return scale * h
 
 
-def _refine_tree(dim: int, R: float, sources_z, scale, h_axis, h_src, max_level: int, h_max: float):
+class LayerCap:
+    """Upper bound on the mesh size from the thickness of horizontal layers: h <= factor * thickness
+    of every layer a cell / point touches (z intervals `edges[k] .. edges[k+1]`).  Without it the
+    size field ignores thin beds, and interface-conforming sampling (make_mesh(interfaces=...))
+    cannot keep boundaries that are closer to each other than the local element size."""
+
+    def __init__(self, edges, factor: float = 1.5):
+        self.edges = np.asarray(edges, dtype=np.float64)
+        cap = factor * np.diff(self.edges)
+        self.cap = np.concatenate([[np.inf], cap, [np.inf]])       # outside the table: no bound
+        # sparse table for range minima
+        self.tab = [self.cap]
+        j = 1
+        while (1 << j) <= len(self.cap):
+            prev = self.tab[-1]
+            self.tab.append(np.minimum(prev[:len(prev) - (1 << (j - 1))], prev[(1 << (j - 1)):]))
+            j += 1
+
+    def interval_min(self, zl, zh):
+        lo = np.searchsorted(self.edges, zl, side="left")          # intervals lo..hi (inclusive) overlap or touch [zl, zh]
+        hi = np.searchsorted(self.edges, zh, side="right")
+        hi = np.maximum(hi, lo)
+        span = hi - lo + 1
+        j = np.floor(np.log2(span)).astype(int)
+        out = np.empty(len(lo))
+        for jj in np.unique(j):
+            m = j == jj
+            t = self.tab[jj]
+            out[m] = np.minimum(t[lo[m]], t[hi[m] - (1 << jj) + 1])
+        return out
+
+    def at(self, z: float) -> float:
+        # on a boundary both neighbours count
+        return float(min(self.cap[int(np.searchsorted(self.edges, z, side="right"))], self.cap[int(np.searchsorted(self.edges, z, side="left"))]))
+
+
+def _refine_tree(dim: int, R: float, sources_z, scale, h_axis, h_src, max_level: int, h_max: float, layer_cap=None):
     """Breadth-first graded quadtree / octree.  Returns leaves as (integer origin [m, dim], level[m])."""
     # root cells have side R; axis and symmetry plane lie on cell boundaries at every level.
     if dim == 2:
@@ -96,7 +132,10 @@ def _refine_tree(dim: int, R: float, sources_z, scale, h_axis, h_src, max_level:
         for zs in src:
             dz = np.maximum(np.maximum(zl - zs, zs - zh), 0.0)
             hmin = np.minimum(hmin, 0.5 * (rho_min ** 2 + dz ** 2) + h_src)
-        hmin = 1.5 * np.minimum(scale * hmin, h_max)
+        hmin = np.minimum(scale * hmin, h_max)
+        if layer_cap is not None:
+            hmin = np.minimum(hmin, layer_cap.interval_min(zl, zh))
+        hmin = 1.5 * hmin
         # cells completely outside the ball are dropped
         near = np.where(np.abs(lo) < np.abs(hi), lo, hi)
         near = np.where((lo <= 0) & (hi >= 0), 0.0, near)
@@ -156,7 +195,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
               material_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None, seed: int = 0,
               h_axis: float = 0.1, h_src: float = 0.01, max_level: int = 18,
               snap_z: Sequence[float] = (), h_max: Optional[float] = None, jitter: float = 0.12,
-              improve_passes: int = 6, interfaces: Sequence[np.ndarray] = ()) -> Mesh:
+              improve_passes: int = 6, interfaces: Sequence[np.ndarray] = (), layer_cap: Optional["LayerCap"] = None) -> Mesh:
     """Graded Delaunay mesh of the reference's half disc (dim=2) or half ball (dim=3).
 
     sources_z : axis positions of current electrodes (refinement centres, snapped to vertices)
@@ -166,6 +205,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     h_max     : cap on the size field (default R/5; keeps the polyhedral outer boundary round)
     jitter    : seeded displacement of interior lattice points, fraction of the local cell size
     improve_passes : sliver-removal passes (3D): perturb vertices of elements with quality < 0.15, re-triangulate
+    layer_cap  : LayerCap bounding the size by the thickness of the layers (thin beds)
     interfaces : (2D only) polylines [(r, z), ...] that must be unions of mesh edges (material
                  interfaces).  They are sampled at ~0.6 h and lattice points closer than 0.8 of that
                  spacing are removed, which makes every sub-segment a Gabriel - hence Delaunay - edge.
@@ -175,7 +215,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     rng = np.random.default_rng(seed)
     if h_max is None:
         h_max = 0.2 * R
-    origins, levels = _refine_tree(dim, R, sources_z, scale, h_axis, h_src, max_level, h_max)
+    origins, levels = _refine_tree(dim, R, sources_z, scale, h_axis, h_src, max_level, h_max, layer_cap)
     pts, hs, isc = _lattice_points(dim, R, origins, levels, max_level)
 
     rad = np.sqrt((pts ** 2).sum(1))
@@ -204,7 +244,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     # conforming interfaces (2D): sample the polylines, clear a corridor around them
     n_iface = 0
     if dim == 2 and len(interfaces):
-        ip, isp = [], []
+        ip, isp, isv = [], [], []          # points, local spacing, 1 for polyline vertices / junctions
         src_list = [float(v) for v in sources_z]
         import math
 
@@ -213,7 +253,10 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
             hq = rho + h_axis
             for zs in src_list:
                 hq = min(hq, 0.5 * (rho * rho + (z_ - zs) ** 2) + h_src)
-            return 0.6 * min(scale * hq, h_max)
+            hq = min(scale * hq, h_max)
+            if layer_cap is not None:
+                hq = min(hq, layer_cap.at(z_))
+            return 0.6 * hq
 
         for poly in interfaces:
             pl = [(float(p_[0]), float(p_[1])) for p_ in np.asarray(poly, dtype=np.float64)]
@@ -237,18 +280,22 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
                 while pos < L:
                     qr_, qz_ = ar + (pos / L) * (br - ar), az + (pos / L) * (bz - az)
                     hq = h_at(qr_, qz_)
-                    ip.append((qr_, qz_)); isp.append(min(hq, L))
+                    ip.append((qr_, qz_)); isp.append(min(hq, L)); isv.append(1 if pos == 0.0 else 0)
                     pos += hq
                     if L - pos < 0.5 * hq:      # avoid a short last piece: the end point closes the segment
                         break
-                ip.append((br, bz)); isp.append(min(hq, L))
-        ip = np.array(ip, dtype=np.float64); isp = np.array(isp)
+                ip.append((br, bz)); isp.append(min(hq, L)); isv.append(1)
+        ip = np.array(ip, dtype=np.float64); isp = np.array(isp); isv = np.array(isv)
         # merge coincident / very close interface points (junctions are listed by both polylines):
-        # of two points closer than 0.3 of their spacing the later one goes
+        # of two points closer than 0.3 of their spacing a marching point yields to a polyline vertex,
+        # otherwise the later one goes
         ti = cKDTree(ip)
         dd2, ii2 = ti.query(ip, k=2)
-        close = dd2[:, 1] < 0.3 * np.minimum(isp, isp[ii2[:, 1]])
-        keep_i = ~(close & (np.arange(len(ip)) > ii2[:, 1]))
+        nn = ii2[:, 1]
+        close = dd2[:, 1] < 0.3 * np.minimum(isp, isp[nn])
+        me = np.arange(len(ip))
+        loses = (isv < isv[nn]) | ((isv == isv[nn]) & (me > nn))
+        keep_i = ~(close & loses)
         ip, isp = ip[keep_i], isp[keep_i]
         ti = cKDTree(ip)
         dnn, inn = ti.query(pts)

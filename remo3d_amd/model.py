@@ -46,7 +46,10 @@ def default_mesh_provider(scale: float = 1.0, seed: int = 0) -> Callable:
             # Example_01 log 7e-2 -> 5e-3, median 9e-4 -> 3e-4; it costs 2.5x the triangles, which is cheap in 2D)
             polys = meshgen.layer_interfaces_2d(local_formation_geometry, local_borehole_geometry, domain_radius)
             inside = [z for z in list(cur) + list(pot) if abs(z) < domain_radius]
-            return meshgen.make_mesh(2, domain_radius, sources_z=inside, scale=scale, seed=seed, interfaces=polys, material_fn=fn)
+            fg = np.asarray(local_formation_geometry, dtype=float)
+            cap = meshgen.LayerCap(np.concatenate([fg[:1, 0], fg[:, 1]]))     # thin beds bound the element size
+            return meshgen.make_mesh(2, domain_radius, sources_z=inside, scale=scale, seed=seed, interfaces=polys, material_fn=fn,
+                                     layer_cap=cap)
         key = (dim, float(domain_radius), tuple(np.round(cur, 4)), tuple(np.round(pot, 4)), float(scale), seed)
         base = cache.get(key)
         if base is None:

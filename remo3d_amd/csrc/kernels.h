@@ -21,14 +21,14 @@ struct PcgBuffers {
     const double *dinv;     // [n]
     double *part_pq;        // [kMaxPartialBlocks*8] per-workgroup partial sums of <p, Ap>
     double *part_rz;        // [2][kMaxPartialBlocks*8] per-workgroup partial sums of <Cr, r> (even / odd step)
-    double *rz0;            // [32] totals forwarded between launches: <Cr0,r0>[8] | <p,Ap>[8] | <Cr,r> of even / odd steps [8+8]
+    double *rz0;            // [40] totals forwarded between launches: <Cr0,r0>[8] | <p,Ap>[8] | <Cr,r> of even / odd steps [8+8] | done flag
     // two-level preconditioner (vertex-block Chebyshev); cheb_degree = 0 -> Jacobi
     int64_t nv_coarse;      // free vertex dofs = size of the leading P1 block
     int cheb_degree;
     double cheb_lmax, cheb_lmin;
     double *cz, *cres;      // [nv_coarse*k]
     double *cd[2];          // [nv_coarse*k] ping-pong Chebyshev directions
-    PcgProgress *progress;  // mapped host ring [progress_len]
+    PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
 };
@@ -55,7 +55,7 @@ int vec_grid(int64_t n);
 void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 threads, 3 mapping, 4 grid (0 = default)
 int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
-void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nblocks, hipStream_t s);
+void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, const double *scal, int nblocks, hipStream_t s);
 
 void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers &b, hipStream_t s);       // + C r0, p0
 void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);  // + C r (Chebyshev steps)

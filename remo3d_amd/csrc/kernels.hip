@@ -88,6 +88,11 @@ template <int K> __device__ __forceinline__ double pick(const double (&a)[K], in
     return r;
 }
 
+// scal[kDoneSlot] (as int) is raised by the update launch once every column is frozen; the remaining
+// launches the host has already queued (it runs a few steps ahead of the device) then return at once.
+constexpr int kDoneSlot = 4 * 8;
+__device__ __forceinline__ bool solve_done(const double *scal) { return reinterpret_cast<const int *>(scal + kDoneSlot)[0] != 0; }
+
 // ------------------------------------------------------------------------------------------
 // metric terms: one thread per element (ngsolve_functions.py:33-36: the coefficient part of the
 // integrand; sigma per material as worker.py:101)
@@ -259,7 +264,8 @@ __device__ __forceinline__ RowWalk row_walk(int mapping, int64_t n, int64_t nnz,
 template <int K, int LPR, bool DOT>
 __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
                                               const int32_t *__restrict__ col, const double *__restrict__ val,
-                                              const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+                                              const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
+    if (scal && solve_done(scal)) return;
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
@@ -309,7 +315,8 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mappin
 template <int K, int LPR, bool DOT>
 __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ col, const double *__restrict__ val,
-                                                   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+                                                   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
+    if (scal && solve_done(scal)) return;
     constexpr int U = 2;
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
@@ -420,7 +427,8 @@ template <int K> struct Chunks {
 template <int K, int LPR, bool DOT>
 __global__ void __launch_bounds__(512) k_spmm_chunk(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ col, const double *__restrict__ val,
-                                                    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part) {
+                                                    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
+    if (scal && solve_done(scal)) return;
     constexpr int CH = Chunks<K>::CH, LQ = Chunks<K>::LQ, NZ = LPR / LQ;  // NZ entries per row pass
     static_assert(LPR >= LQ && LPR <= 64, "lanes per row");
     const int rpb = blockDim.x / LPR;
@@ -532,7 +540,7 @@ int spmv_grid(int64_t n, int lpr) {
     return int(g);
 }
 
-template <int K> static void spmm_dispatch(const CsrView &A, const double *x, double *y, double *part, int nb, hipStream_t s) {
+template <int K> static void spmm_dispatch(const CsrView &A, const double *x, double *y, double *part, const double *scal, int nb, hipStream_t s) {
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
     const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 0;
@@ -541,14 +549,14 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
     constexpr int LQ = Chunks<K>::LQ;
 #define REMO_SPMM(KERNEL, L)                                                                                                          \
     if (part)                                                                                                                         \
-        hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part); \
+        hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
     else                                                                                                                              \
-        hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part)
+        hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part); \
+        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part)
+        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal)
     if (variant == 3) {
         if (lpr >= 32) { REMO_SPMM_PAIR(32); }
         else if (lpr == 16) { REMO_SPMM_PAIR(16); }
@@ -571,16 +579,16 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
 #undef REMO_SPMM_PAIR
 }
 
-void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, int nb, hipStream_t s) {
+void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, const double *scal, int nb, hipStream_t s) {
     switch (k) {
-        case 1: spmm_dispatch<1>(A, x, y, part, nb, s); break;
-        case 2: spmm_dispatch<2>(A, x, y, part, nb, s); break;
-        case 3: spmm_dispatch<3>(A, x, y, part, nb, s); break;
-        case 4: spmm_dispatch<4>(A, x, y, part, nb, s); break;
-        case 5: spmm_dispatch<5>(A, x, y, part, nb, s); break;
-        case 6: spmm_dispatch<6>(A, x, y, part, nb, s); break;
-        case 7: spmm_dispatch<7>(A, x, y, part, nb, s); break;
-        default: spmm_dispatch<8>(A, x, y, part, nb, s); break;
+        case 1: spmm_dispatch<1>(A, x, y, part, scal, nb, s); break;
+        case 2: spmm_dispatch<2>(A, x, y, part, scal, nb, s); break;
+        case 3: spmm_dispatch<3>(A, x, y, part, scal, nb, s); break;
+        case 4: spmm_dispatch<4>(A, x, y, part, scal, nb, s); break;
+        case 5: spmm_dispatch<5>(A, x, y, part, scal, nb, s); break;
+        case 6: spmm_dispatch<6>(A, x, y, part, scal, nb, s); break;
+        case 7: spmm_dispatch<7>(A, x, y, part, scal, nb, s); break;
+        default: spmm_dispatch<8>(A, x, y, part, scal, nb, s); break;
     }
 }
 
@@ -646,6 +654,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
     double *scal = rz0;
+    if (solve_done(scal)) return;
     double pq[K], rz[K], unused[K], alpha[K], acc[K];
     if (step == 0) {
         reduce_partials3<K>(part_pq, nb_spmv, part_rz_cur, nb_rz, nullptr, 0, pq, rz, unused, smem);
@@ -662,13 +671,23 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         acc[c] = 0.0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        bool any_live = false;
+#pragma unroll
+        for (int c = 0; c < K; ++c) any_live |= (alpha[c] != 0.0);
+        if (!any_live) {   // every column frozen: later launches of this solve are no-ops; tell the host where it ended
+            reinterpret_cast<int *>(scal + kDoneSlot)[0] = 1;
+            PcgProgress *dn = progress + (progress_len - 1);
+#pragma unroll
+            for (int c = 0; c < K; ++c) __hip_atomic_store(&dn->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dn->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 #pragma unroll
         for (int c = 0; c < K; ++c) scal[8 + c] = pq[c];
         if (step == 0)
 #pragma unroll
             for (int c = 0; c < K; ++c) { rz0[c] = rz[c]; scal[16 + c] = rz[c]; }
         // progress record in mapped host memory: data first, then the step number (system scope)
-        PcgProgress *pr = progress + (step % progress_len);
+        PcgProgress *pr = progress + (step % (progress_len - 1));   // the last slot is the "done" record
 #pragma unroll
         for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -700,8 +719,9 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
                                                    const double *__restrict__ val, const double *__restrict__ dinv,
                                                    const double *__restrict__ d_old, double *__restrict__ d_new,
                                                    double *__restrict__ z, double *__restrict__ res, double c1, double c2, double inv_theta,
-                                                   const double *__restrict__ r, double *__restrict__ part) {
+                                                   const double *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
     constexpr int LPR = 8, RPB = 256 / LPR;
+    if (solve_done(scal)) return;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     double dot[K];
 #pragma unroll
@@ -751,6 +771,7 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
                                                        const double *__restrict__ r, double *__restrict__ p,
                                                        const double *__restrict__ dinv) {
     __shared__ double smem[16 * K];
+    if (solve_done(scal)) return;
     double beta[K];
     if (first) {  // p0 = C r0
 #pragma unroll
@@ -780,13 +801,14 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_rz, const double *__restrict__ part_rz, PcgProgress *progress,
-                                                   int progress_len) {
+__global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_rz, const double *__restrict__ part_rz, const double *__restrict__ scal,
+                                                   PcgProgress *progress, int progress_len) {
     __shared__ double smem[16 * K];
+    if (solve_done(scal)) return;   // the "done" record already holds the final <Cr,r>
     double rz[K];
     reduce_partials<K>(part_rz, nb_rz, rz, smem);
     if (threadIdx.x == 0) {
-        PcgProgress *pr = progress + (step % progress_len);
+        PcgProgress *pr = progress + (step % (progress_len - 1));
 #pragma unroll
         for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -870,7 +892,7 @@ static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *pa
         const bool first = (j == 0), last = (j + 1 == b.cheb_degree);
 #define REMO_CHEB(F, L)                                                                                                                          \
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
-                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part))
+                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0))
         if (first && last) { REMO_CHEB(true, true); }
         else if (first) { REMO_CHEB(true, false); }
         else if (last) { REMO_CHEB(false, true); }
@@ -912,7 +934,7 @@ void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const 
 
 void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s) {
     const double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_final<KK>, dim3(1), dim3(256), 0, s, step, nb_rz(b), cur, b.progress, b.progress_len));
+    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_final<KK>, dim3(1), dim3(256), 0, s, step, nb_rz(b), cur, b.rz0, b.progress, b.progress_len));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -116,25 +116,6 @@ int fail(remo_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
-// spin on the mapped progress record until the device has reached `step`; falls back to a
-// stream synchronisation (which also publishes the record) after `timeout_ms`.
-bool wait_progress(remo_ctx *ctx, int step, double timeout_ms) {
-    volatile int32_t *flag = &ctx->progress[step % ctx->progress_len].step;
-    const double t0 = now_ms();
-    int spins = 0;
-    while (*flag != step) {
-        if (++spins > 64) {
-            std::this_thread::yield();
-            if (now_ms() - t0 > timeout_ms) {
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                return *flag == step;
-            }
-        }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    return true;
-}
-
 struct ChunkResult {
     int steps = 0;
     bool converged = false;
@@ -152,57 +133,73 @@ ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, P
     const int check = o.check_every > 0 ? o.check_every : 10;
     for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
+    HIP_TRY(hipMemsetAsync(buf.rz0, 0, 40 * sizeof(double), s));   // forwarded totals + done flag
     launch_pcg_init(A, k, d_f, buf, s);
+    volatile int32_t *done_step = &ctx->progress[ctx->progress_len - 1].step;
     int step = 0;
     bool done = false;
     for (; step < maxit && !done;) {
         if (o.time_kernels && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
-            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.nb_spmv, s);
+            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.rz0, buf.nb_spmv, s);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
             ev_used += 2;
         } else {
-            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.nb_spmv, s);
+            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.rz0, buf.nb_spmv, s);
         }
         launch_pcg_update(A, k, step, tol2, buf, s);
         launch_pcg_direction(A, k, step, tol2, buf, s);
         ++step;
+        if (*done_step >= 0) { done = true; break; }   // the device froze every column: the queued launches are no-ops
         if (step % check == 0) {
-            const int target = step - 2 * check;  // stay two checks ahead of the device
+            // stay one check interval ahead of the device (a step is ~10 launches, ~30 us of host time
+            // against ~150 us on the device); the wait also ends when the "done" record appears
+            const int target = step - check;
             if (target >= 0) {
-                if (!wait_progress(ctx, target, 2000.0)) throw std::runtime_error("PCG progress record not visible to the host");
-                const PcgProgress &pr = ctx->progress[target % ctx->progress_len];
-                const PcgProgress &p0 = ctx->progress[0];
-                bool all = true;
-                for (int c = 0; c < k; ++c) {
-                    const double r = pr.rz[c];
-                    if (!std::isfinite(r)) { res.finite = false; all = true; break; }
-                    if (r > tol2 * p0.rz[c]) all = false;
+                volatile int32_t *flag = &ctx->progress[target % (ctx->progress_len - 1)].step;
+                const double t0 = now_ms();
+                int spins = 0;
+                while (*flag != target && *done_step < 0) {
+                    if (++spins > 64) {
+                        std::this_thread::yield();
+                        if (now_ms() - t0 > 2000.0) {
+                            HIP_TRY(hipStreamSynchronize(s));
+                            if (*flag != target && *done_step < 0) throw std::runtime_error("PCG progress record not visible to the host");
+                        }
+                    }
                 }
-                if (all) done = true;
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (*done_step >= 0) { done = true; break; }
+                const PcgProgress &pr = ctx->progress[target % (ctx->progress_len - 1)];
+                for (int c = 0; c < k; ++c)
+                    if (!std::isfinite(pr.rz[c])) { res.finite = false; done = true; }
             }
         }
     }
     launch_pcg_final(k, step, buf, s);
     HIP_TRY(hipStreamSynchronize(s));
-    res.steps = step;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const PcgProgress &dn = ctx->progress[ctx->progress_len - 1];
+    const int last = (dn.step >= 0) ? dn.step : step;   // index of the record that holds the final <Cr,r>
+    const PcgProgress &fin = (dn.step >= 0) ? dn : ctx->progress[step % (ctx->progress_len - 1)];
+    res.steps = (dn.step >= 0) ? dn.step : step;
     const PcgProgress &p0 = ctx->progress[0];
     res.converged = true;
     for (int c = 0; c < k; ++c) {
-        res.iters[c] = step;
+        res.iters[c] = last;
         const double r0 = p0.rz[c];
-        for (int i = 0; i <= step; ++i) {
-            const PcgProgress &pr = ctx->progress[i % ctx->progress_len];
-            if (pr.step != i) continue;
+        for (int i = 0; i <= last; ++i) {
+            const PcgProgress &pr = (i == last) ? fin : ctx->progress[i % (ctx->progress_len - 1)];
+            if (i != last && pr.step != i) continue;
             if (!std::isfinite(pr.rz[c])) res.finite = false;
             if (!(pr.rz[c] > tol2 * r0)) { res.iters[c] = i; break; }
         }
-        const double rl = ctx->progress[step % ctx->progress_len].rz[c];
+        const double rl = fin.rz[c];
         res.relres[c] = (r0 > 0.0) ? std::sqrt(rl / r0) : 0.0;
         if (rl > tol2 * r0) res.converged = false;
         if (!std::isfinite(rl)) res.finite = false;
     }
-    if (st) st->pcg_steps += step;
+    if (st) st->pcg_steps += res.steps;
     return res;
 }
 
@@ -218,7 +215,7 @@ void remo_opts_default(remo_opts_t *o) {
     o->preconditioner = 1;  // remo3d.py:82 default "multigrid" => best available
     o->condense = 1;        // remo3d.py:83
     o->maxsteps = 1000;     // ngsolve_functions.py:50
-    o->check_every = 10;
+    o->check_every = 5;
     o->rtol = 1e-8;         // NGSolve CGSolver default precision
     o->time_kernels = 0;
     o->coarse_degree = 6;
@@ -405,7 +402,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.dinv = d_dinv;
         buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
         buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
-        buf.rz0 = ctx->take<double>(32);
+        buf.rz0 = ctx->take<double>(40);
         const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
         buf.nv_coarse = two_level ? sy.nvfree : 0;
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : 6) : 0;
@@ -417,7 +414,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         double *d_pz = ctx->take<double>(npts + 1), *d_pI = ctx->take<double>(npts + 1);
         int32_t *d_prhs = ctx->take<int32_t>(npts + 1), *d_found = ctx->take<int32_t>(npts + 1);
         double *d_phi = ctx->take<double>(size_t(npts + 1) * N), *d_fint = ctx->take<double>(npts + 1), *d_out = ctx->take<double>(npts + 1);
-        ctx->ensure_progress(o.maxsteps + 2);
+        ctx->ensure_progress(o.maxsteps + 3);
         buf.progress = ctx->progress_dev;
         buf.progress_len = ctx->progress_len;
         if (o.time_kernels && ctx->spmv_ev.size() < 8192) {
@@ -654,9 +651,9 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dy), sizeof(double) * n * k));
         HIP_TRY(hipMemcpy(dx, x, sizeof(double) * n * k, hipMemcpyHostToDevice));
         const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
-        launch_spmm(b->A, k, dx, dy, nullptr, nb, ctx->stream);  // warm-up
+        launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);  // warm-up
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        for (int r = 0; r < reps; ++r) launch_spmm(b->A, k, dx, dy, nullptr, nb, ctx->stream);
+        for (int r = 0; r < reps; ++r) launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         float ms = 0;

@@ -24,7 +24,7 @@ class RemoError(RuntimeError):
         self.code = code
 
 
-def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=10,
+def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
               time_kernels=False, coarse_degree=0, coarse_ratio=0) -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50)."""
     L = _lib.load()

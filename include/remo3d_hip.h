@@ -161,9 +161,10 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
                        int32_t *rowptr /*[n_free+1] or NULL*/, int32_t *col /*[nnz] or NULL*/,
                        int32_t *freeid /*[n_dof] or NULL*/);
 
-/* Kernel tuning knob for the probe scripts (profiles/): key 0 SpMM variant (1 lane per nonzero,
- * 2 chunk lanes), 1 lanes per row, 2 threads per workgroup, 3 row mapping (0 grid-stride, 1
- * XCD-aware), 4 grid size; value 0 (mapping: -1) restores the default.  Process-global. */
+/* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
+ * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row mapping of
+ * variant 1 (0 grid-stride, 1 XCD-aware ranges, 2 / 3 per-workgroup blocked ranges), 4 grid size;
+ * value 0 (mapping: -1) restores the default.  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

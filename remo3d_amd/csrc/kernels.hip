@@ -218,14 +218,6 @@ __device__ __forceinline__ int64_t row_of_offset(const int32_t *__restrict__ row
     return lo;
 }
 
-struct d2 { double a, b; };
-// 16 bytes from an 8-byte-aligned address: one global_load_dwordx4 (gfx950 runs in unaligned-access mode)
-__device__ __forceinline__ d2 load16(const double *p) {
-    d2 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-
 // Row walk shared by the SpMM variants.  mapping 0: plain grid-stride over row groups.
 // mapping 1 (XCD-aware, speed only): workgroups b and b + 8 share an XCD and its 4 MiB L2, so
 // each residue class mod 8 walks one contiguous, nnz-balanced row range and the x rows it gathers
@@ -412,98 +404,9 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
     }
 }
 
-// Variant B ("chunk lanes"): a fully divergent gather costs the texture-address path one cache
-// line visit per lane and instruction, so K 8-byte loads per stored entry visit ~5 K lines per 64
-// entries.  Here LQ = 1/2/4 adjacent lanes share one stored entry and each loads ONE 16-byte chunk
-// (two columns) of its x row: one instruction serves 64/LQ entries and all their columns, adjacent
-// lanes hit the same line, and every lane carries two accumulators instead of K.  The K interleaved
-// right-hand sides stay compact ([n][K], 8-byte aligned rows); for odd K the last chunk's second
-// half is the next row's first value (read, never used; buffers carry 16 bytes of slack).
-template <int K> struct Chunks {
-    static constexpr int CH = (K + 1) / 2;                       // 16-byte chunks per x row
-    static constexpr int LQ = (CH <= 1) ? 1 : ((CH <= 2) ? 2 : 4);  // lanes per stored entry
-};
-
-template <int K, int LPR, bool DOT>
-__global__ void __launch_bounds__(512) k_spmm_chunk(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
-                                                    const int32_t *__restrict__ col, const double *__restrict__ val,
-                                                    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
-    if (scal && solve_done(scal)) return;
-    constexpr int CH = Chunks<K>::CH, LQ = Chunks<K>::LQ, NZ = LPR / LQ;  // NZ entries per row pass
-    static_assert(LPR >= LQ && LPR <= 64, "lanes per row");
-    const int rpb = blockDim.x / LPR;
-    const int sub = threadIdx.x % LPR;
-    const int grp = threadIdx.x / LPR;
-    const int q = sub % LQ;       // which chunk of the x row
-    const int slot = sub / LQ;    // which entry of the pass
-    const bool active = q < CH;
-    const bool second = (2 * q + 1) < K;
-    const RowWalk w = row_walk(mapping, n, nnz, rowptr, rpb, grp);
-    double dot0 = 0.0, dot1 = 0.0;
-    for (int64_t row = w.begin; row < w.end; row += w.step) {
-        const int32_t rs = rowptr[row], re = rowptr[row + 1];
-        double acc0 = 0.0, acc1 = 0.0;
-        int32_t p = rs + slot;
-        for (; p + NZ < re; p += 2 * NZ) {  // two entries in flight per lane
-            const double v0 = val[p], v1 = val[p + NZ];
-            const int64_t j0 = col[p], j1 = col[p + NZ];
-            if (active) {
-                const d2 a = load16(x + j0 * K + 2 * q);
-                const d2 b = load16(x + j1 * K + 2 * q);
-                acc0 += v0 * a.a; acc1 += v0 * a.b;
-                acc0 += v1 * b.a; acc1 += v1 * b.b;
-            }
-        }
-        if (p < re) {
-            const double v0 = val[p];
-            const int64_t j0 = col[p];
-            if (active) {
-                const d2 a = load16(x + j0 * K + 2 * q);
-                acc0 += v0 * a.a; acc1 += v0 * a.b;
-            }
-        }
-#pragma unroll
-        for (int off = LQ; off < LPR; off <<= 1) {
-            acc0 += __shfl_xor(acc0, off, 64);
-            acc1 += __shfl_xor(acc1, off, 64);
-        }
-        if (slot == 0 && active) {
-            y[row * K + 2 * q] = acc0;
-            if (second) y[row * K + 2 * q + 1] = acc1;
-            if (DOT) {
-                const d2 xr = load16(x + row * K + 2 * q);
-                dot0 += acc0 * xr.a;
-                if (second) dot1 += acc1 * xr.b;
-            }
-        }
-    }
-    if (DOT) {
-        // lanes with equal q hold partial sums of columns (2q, 2q+1): fold the wave over the
-        // other lane bits, then the waves of the block through LDS (fixed order: deterministic)
-        __shared__ double smem[16 * 2 * LQ];
-#pragma unroll
-        for (int off = LQ; off < 64; off <<= 1) {
-            dot0 += __shfl_xor(dot0, off, 64);
-            dot1 += __shfl_xor(dot1, off, 64);
-        }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        if (lane < LQ) {
-            smem[(wave * LQ + lane) * 2] = dot0;
-            smem[(wave * LQ + lane) * 2 + 1] = dot1;
-        }
-        __syncthreads();
-        if (threadIdx.x < K) {
-            const int c = threadIdx.x;
-            double sum = 0.0;
-            for (int wv = 0; wv < nw; ++wv) sum += smem[(wv * LQ + (c >> 1)) * 2 + (c & 1)];
-            part[blockIdx.x * K + c] = sum;
-        }
-    }
-}
-
 // tuning knobs (remo_debug_tune): 0 = heuristic default
 struct SpmmTuning {
-    int variant = 0;  // 1 = lane per nonzero, 2 = chunk lanes, 3 = edge row pairs
+    int variant = 0;  // 1 = lane per stored entry, 3 = edge row pairs (default)
     int lpr = 0;
     int threads = 0;
     int mapping = -1;
@@ -546,7 +449,6 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
     const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 0;
     int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
-    constexpr int LQ = Chunks<K>::LQ;
 #define REMO_SPMM(KERNEL, L)                                                                                                          \
     if (part)                                                                                                                         \
         hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
@@ -562,18 +464,11 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
         else if (lpr == 16) { REMO_SPMM_PAIR(16); }
         else if (lpr == 8) { REMO_SPMM_PAIR(8); }
         else { REMO_SPMM_PAIR(4); }
-    } else if (variant == 1) {
+    } else {
         if (lpr >= 32) { REMO_SPMM(k_spmm, 32); }
         else if (lpr == 16) { REMO_SPMM(k_spmm, 16); }
         else if (lpr == 8) { REMO_SPMM(k_spmm, 8); }
         else { REMO_SPMM(k_spmm, 4); }
-    } else {
-        if (lpr < LQ) lpr = LQ;
-        if (lpr >= 64) { REMO_SPMM(k_spmm_chunk, 64); }
-        else if (lpr == 32) { REMO_SPMM(k_spmm_chunk, 32); }
-        else if (lpr == 16) { REMO_SPMM(k_spmm_chunk, 16); }
-        else if (lpr == 8) { REMO_SPMM(k_spmm_chunk, 8); }
-        else { REMO_SPMM(k_spmm_chunk, 4); }
     }
 #undef REMO_SPMM
 #undef REMO_SPMM_PAIR

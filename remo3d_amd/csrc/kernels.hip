@@ -27,6 +27,76 @@ template <int W> __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// ---- transposing reduction ---------------------------------------------------------------
+// A group of W lanes holds M partial values per lane and needs the M group sums.  Summing each value
+// with its own butterfly costs M log2(W) lane exchanges, and on gfx9 a __shfl is a ds_bpermute through
+// the LDS pipe that all four SIMDs share: for the SpMM (M = 10 values per edge-row pair) that pipe,
+// not HBM, set the kernel time.  Here every exchange step HALVES the value list instead: the two
+// halves of the group keep one value of each pair and send the other, so the whole reduction costs
+// M - 1 + (odd leftovers) exchanges, all of them DPP moves inside a 16-lane row (VALU, no LDS), and
+// ends with the sums spread over the lanes, one (or ceil(M / W)) per lane, which also turns the M
+// serial stores of lane 0 into one coalesced store.
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// value of the partner lane in the other half of the W-lane group (a bijection between the halves)
+template <int W> __device__ __forceinline__ double partner(double v) {
+    if constexpr (W == 16) return dpp_mov<0x140>(v);      // row_mirror: i <-> 15 - i
+    else if constexpr (W == 8) return dpp_mov<0x141>(v);  // row_half_mirror: i <-> 7 - i
+    else if constexpr (W == 4) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    else if constexpr (W == 2) return dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    else return __shfl_xor(v, W / 2, 64);
+}
+constexpr int treduce_out(int m, int w) { return w < 2 ? m : treduce_out((m + 1) / 2, w / 2); }
+// In place: on return v[0 .. treduce_out(M, W)) are complete group sums; which ones, per lane, is
+// given by TOwner below (same recursion on indices).  Fixed order: deterministic.
+template <int M, int W> struct TReduce {
+    static __device__ __forceinline__ void run(double *v, int sub) {
+        if constexpr (W >= 2) {
+            const bool hi = (sub & (W / 2)) != 0;
+            constexpr int P = M / 2;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const double a = v[2 * j], b = v[2 * j + 1];
+                v[j] = (hi ? b : a) + partner<W>(hi ? a : b);
+            }
+            if constexpr (M & 1) {
+                const double l = v[M - 1];
+                v[P] = l + partner<W>(l);
+            }
+            TReduce<(M + 1) / 2, W / 2>::run(v, sub);
+        }
+    }
+};
+// idx[f] = index (0 .. M-1) of the original value whose sum lane `sub` holds in v[f] after TReduce;
+// an odd leftover is carried by both halves, and only the lane that took the low half every time it
+// was carried is its owner (own[f]), so that each sum is stored exactly once.
+template <int M, int W> struct TOwner {
+    static __device__ __forceinline__ void run(int *idx, int *own, int sub) {
+        if constexpr (W >= 2) {
+            const int hi = (sub & (W / 2)) != 0;   // arithmetic blends: keeps the arrays in registers
+            constexpr int P = M / 2;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                idx[j] = idx[2 * j] + hi * (idx[2 * j + 1] - idx[2 * j]);
+                own[j] = own[2 * j] + hi * (own[2 * j + 1] - own[2 * j]);
+            }
+            if constexpr (M & 1) {
+                idx[P] = idx[M - 1];
+                own[P] = own[M - 1] * (1 - hi);
+            }
+            TOwner<(M + 1) / 2, W / 2>::run(idx, own, sub);
+        }
+    }
+};
+template <int M, int W> __device__ __forceinline__ void towner_init(int (&idx)[M], int (&own)[M], int sub) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) { idx[j] = j; own[j] = 1; }
+    TOwner<M, W>::run(idx, own, sub);
+}
+
 // Sum K per-thread values over the block (blockDim.x multiple of 64, <= 1024).  Result valid in
 // every thread.  Deterministic: fixed tree.
 template <int K> __device__ __forceinline__ void block_sum(double (&v)[K], double *smem /* [16*K] */) {
@@ -304,20 +374,27 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mappin
 // passes of its row up front and then all U gathers, before any arithmetic: a row of <= U * LPR
 // entries pays the two latencies once instead of once per pass.  Lanes past the row end read a
 // safe address with a zero value (no branches between the loads).
-template <int K, int LPR, bool DOT>
-__global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
+template <int K, int LPR, bool DOT, int MODE = 0>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
+__global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, int xcd_windows, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ col, const double *__restrict__ val,
                                                    const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
     if (scal && solve_done(scal)) return;
     constexpr int U = 2;
+    constexpr int MFP = treduce_out(2 * K, LPR), MFS = treduce_out(K, LPR);   // sums per lane after the reduction
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
     const int64_t npair = (pair_end - pair_begin) >> 1;
     const int64_t ngroups = n - npair;
-    double dot[K];
+    // which of the 2K (pair) / K (single row) sums this lane ends up with: entry t of a pair is y[row*K + t]
+    int idx_p[2 * K], idx_s[K], own_p[2 * K], own_s[K];
+    towner_init<2 * K, LPR>(idx_p, own_p, sub);
+    towner_init<K, LPR>(idx_s, own_s, sub);
+    double dot_p[MFP], dot_s[MFS];
 #pragma unroll
-    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    for (int f = 0; f < MFP; ++f) dot_p[f] = 0.0;
+#pragma unroll
+    for (int f = 0; f < MFS; ++f) dot_s[f] = 0.0;
     // row of lane-group index g (edge rows are taken two at a time)
     auto row_of = [&](int64_t g, bool &pair) -> int64_t {
         pair = false;
@@ -326,7 +403,15 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
         return g + npair;
     };
     const int64_t gstep = int64_t(gridDim.x) * rpb;
-    int64_t g = int64_t(blockIdx.x) * rpb + grp;
+    // xcd_windows: workgroups b, b + 8, ... share an XCD (and its L2); give them neighbouring row
+    // groups of every sweep step, so that an XCD gathers from one window of x instead of all of it
+    int vblock = int(blockIdx.x);
+    if (xcd_windows) {
+        const int per = int(gridDim.x >> 3), slot = int(blockIdx.x >> 3);
+        const int inner = (xcd_windows == 2 && (per & 31) == 0) ? (slot & 31) * (per >> 5) + (slot >> 5) : slot;   // 2: also CU-adjacent (probe)
+        vblock = int(blockIdx.x & 7) * per + inner;
+    }
+    int64_t g = int64_t(vblock) * rpb + grp;
     bool pair_n = false;
     int64_t row_n = (g < ngroups) ? row_of(g, pair_n) : 0;
     int32_t rs_n = (g < ngroups) ? rowptr[row_n] : 0, re_n = (g < ngroups) ? rowptr[row_n + 1] : 0;
@@ -342,9 +427,9 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
             re_n = rowptr[row_n + 1];
         }
         const int32_t len = pair ? re - rs : 0;   // the second row's values sit `len` entries further
-        double acc0[K], acc1[K];
+        double acc[2 * K];                        // [0, K): row, [K, 2K): row + 1
 #pragma unroll
-        for (int c = 0; c < K; ++c) { acc0[c] = 0.0; acc1[c] = 0.0; }
+        for (int c = 0; c < 2 * K; ++c) acc[c] = 0.0;
         for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {
             int32_t j[U];
             double v0[U], v1[U], xv[U][K];
@@ -363,42 +448,64 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 #pragma unroll
                 for (int c = 0; c < K; ++c) xv[u][c] = 0.0;
                 if (j[u] >= 0) {
-                    const double *xr = x + int64_t(j[u]) * K;
+                    if (MODE == 1) {          // no gather at all
 #pragma unroll
-                    for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+                        for (int c = 0; c < K; ++c) xv[u][c] = double(j[u]);
+                    } else {
+                        const double *xr = x + int64_t(MODE == 2 ? (j[u] & 255) : j[u]) * K;   // 2: L1-resident gather
+#pragma unroll
+                        for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
-                    acc0[c] += v0[u] * xv[u][c];
-                    acc1[c] += v1[u] * xv[u][c];
+                    acc[c] += v0[u] * xv[u][c];
+                    acc[K + c] += v1[u] * xv[u][c];
                 }
         }
+        if (MODE == 3) {   // no reduction, (practically) no store
+            double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < K; ++c) acc0[c] = group_sum<LPR>(acc0[c]);
-        if (pair)
+            for (int c = 0; c < 2 * K; ++c) t += acc[c];
+            if (t == 1.2345e300) y[row * K] = t;
+            continue;
+        }
+        // wave-uniform choice (row classes are contiguous, so all but a handful of waves are uniform)
+        if (__builtin_amdgcn_ballot_w64(pair) != 0) {
+            TReduce<2 * K, LPR>::run(acc, sub);
 #pragma unroll
-            for (int c = 0; c < K; ++c) acc1[c] = group_sum<LPR>(acc1[c]);
-        if (sub == 0) {
+            for (int f = 0; f < MFP; ++f)
+                if (own_p[f] && (pair || idx_p[f] < K)) {
+                    const int64_t at = row * K + idx_p[f];
+                    y[at] = acc[f];
+                    if (DOT) dot_p[f] += acc[f] * x[at];
+                }
+        } else {
+            TReduce<K, LPR>::run(acc, sub);
 #pragma unroll
-            for (int c = 0; c < K; ++c) y[row * K + c] = acc0[c];
-            if (pair)
-#pragma unroll
-                for (int c = 0; c < K; ++c) y[(row + 1) * K + c] = acc1[c];
-            if (DOT) {
-                const double *xr = x + row * K;
-#pragma unroll
-                for (int c = 0; c < K; ++c) dot[c] += acc0[c] * xr[c];
-                if (pair)
-#pragma unroll
-                    for (int c = 0; c < K; ++c) dot[c] += acc1[c] * xr[K + c];
-            }
+            for (int f = 0; f < MFS; ++f)
+                if (own_s[f]) {
+                    const int64_t at = row * K + idx_s[f];
+                    y[at] = acc[f];
+                    if (DOT) dot_s[f] += acc[f] * x[at];
+                }
         }
     }
     if (DOT) {
         __shared__ double smem[16 * K];
+        double dot[K];   // back to one slot per column for the block sum
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            double d = 0.0;
+#pragma unroll
+            for (int f = 0; f < MFP; ++f) d += (idx_p[f] % K == c) ? dot_p[f] : 0.0;
+#pragma unroll
+            for (int f = 0; f < MFS; ++f) d += (idx_s[f] == c) ? dot_s[f] : 0.0;
+            dot[c] = d;
+        }
         block_sum<K>(dot, smem);
         if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
     }
@@ -406,6 +513,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 
 // tuning knobs (remo_debug_tune): 0 = heuristic default
 struct SpmmTuning {
+    int mode = 0;     // ablation mode of the pair kernel (K = 5, 16 lanes per row only)
     int variant = 0;  // 1 = lane per stored entry, 3 = edge row pairs (default)
     int lpr = 0;
     int threads = 0;
@@ -420,6 +528,7 @@ void set_spmm_tuning(int key, int value) {
         case 2: g_tune.threads = value; break;
         case 3: g_tune.mapping = value; break;
         case 4: g_tune.grid = value; break;
+        case 5: g_tune.mode = value; break;
         default: break;
     }
 }
@@ -446,9 +555,10 @@ int spmv_grid(int64_t n, int lpr) {
 template <int K> static void spmm_dispatch(const CsrView &A, const double *x, double *y, double *part, const double *scal, int nb, hipStream_t s) {
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
-    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 0;
     int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
+    // default row mapping: XCD windows for the pair kernel (measured 69 -> 60 us at 329k rows, k = 5), plain grid-stride otherwise
+    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : (variant == 3 ? 1 : 0);
 #define REMO_SPMM(KERNEL, L)                                                                                                          \
     if (part)                                                                                                                         \
         hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
@@ -456,9 +566,17 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
         hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \
+        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal)
+        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
+    if constexpr (K == 5) {
+        if (variant == 3 && lpr == 16 && g_tune.mode >= 1 && g_tune.mode <= 3 && !part) {
+            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            return;
+        }
+    }
     if (variant == 3) {
         if (lpr >= 32) { REMO_SPMM_PAIR(32); }
         else if (lpr == 16) { REMO_SPMM_PAIR(16); }

@@ -734,13 +734,26 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
                                                    double *__restrict__ z, double *__restrict__ res, double c1, double c2, double inv_theta,
                                                    const double *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
     constexpr int LPR = 8, RPB = 256 / LPR;
+    static_assert(K <= LPR, "one column per lane after the transposing reduction");
     if (solve_done(scal)) return;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
-    double dot[K];
-#pragma unroll
-    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    // the kernel is a chain of dependent round trips on a tiny block (launch-latency class): after the
+    // transposing reduction lane `sub` owns column mycol of its row, so the vectors of the update are
+    // requested per lane BEFORE the row is walked and need no round trip of their own
+    int idx[K], own[K];
+    towner_init<K, LPR>(idx, own, sub);
+    const int mycol = idx[0];
+    const bool mine = own[0] != 0;
+    double dot = 0.0;
     for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        const int64_t at = row * K + mycol;
+        double di = 0.0, rr = 0.0, dold_in = 0.0, z_in = 0.0, res_in = 0.0;
+        if (mine) {
+            di = dinv[row];
+            rr = r[at];
+            if (!FIRST) { dold_in = d_old[at]; z_in = z[at]; res_in = res[at]; }
+        }
         double t[K];
 #pragma unroll
         for (int c = 0; c < K; ++c) t[c] = 0.0;
@@ -752,29 +765,28 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
 #pragma unroll
             for (int c = 0; c < K; ++c) t[c] += v * dj[c];
         }
-#pragma unroll
-        for (int c = 0; c < K; ++c) t[c] = group_sum<LPR>(t[c]);
-        if (sub == 0) {
-            const double di = dinv[row];
-#pragma unroll
-            for (int c = 0; c < K; ++c) {
-                const double rr = r[row * K + c];
-                const double dold = FIRST ? di * rr * inv_theta : d_old[row * K + c];
-                const double zi = FIRST ? dold : z[row * K + c] + dold;
-                const double ri = (FIRST ? rr : res[row * K + c]) - t[c];
-                z[row * K + c] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
-                if (!LAST) {
-                    res[row * K + c] = ri;
-                    d_new[row * K + c] = c1 * dold + c2 * di * ri;
-                }
-                if (LAST) dot[c] += rr * zi;
+        TReduce<K, LPR>::run(t, sub);
+        if (mine) {
+            const double dold = FIRST ? di * rr * inv_theta : dold_in;
+            const double zi = FIRST ? dold : z_in + dold;
+            const double ri = (FIRST ? rr : res_in) - t[0];
+            z[at] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
+            if (!LAST) {
+                res[at] = ri;
+                d_new[at] = c1 * dold + c2 * di * ri;
             }
+            if (LAST) dot += rr * zi;
         }
     }
     if (LAST) {
         __shared__ double smem[16 * K];
-        block_sum<K>(dot, smem);
-        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = dot[threadIdx.x];
+        double dcol[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dcol[c] = (mine && c == mycol) ? dot : 0.0;
+        block_sum<K>(dcol, smem);
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+            if (threadIdx.x == c) part[blockIdx.x * K + c] = dcol[c];
     }
 }
 

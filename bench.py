@@ -79,10 +79,10 @@ def cpu_baseline(work, rtol, budget_rhs=1):
 
 
 def pmc_traffic(workload, n_free, nnz):
-    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    this exact workload (profiles/, collected with tools/pmc_traffic.py); None when the run differs."""
+    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this exact workload
+    (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_default_bench.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_default_bench.json")) as f:
             p = json.load(f)
     except OSError:
         return None
@@ -180,7 +180,7 @@ def main():
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     empty_event_pair_us=1e3 * agg.get("ev_over", 0.0),
-                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)", traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_b_pmc_traffic_default_bench.json")
+                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_c_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f64", data="synthetic",

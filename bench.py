@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxsteps", type=int, default=1000)
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
+                    help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
     args = ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     work = wl["work"]
     ctx = solver.Context(local)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
-                            time_kernels=not args.no_events)
+                            time_kernels=not args.no_events, precision=args.precision)
     resident = [ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for w in work]
     n_tools = len(wl["names"])
 
@@ -176,18 +178,18 @@ def main():
     roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
                     traffic=pmc_traffic(f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
                                         int(agg["n"]), int(agg["nnz"])),
-                    kernel="k_spmm (CSR SpMM, fp64, k=5 interleaved RHS)", launches=int(agg["spmv_launches"]),
+                    kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if args.precision == "fp64" else "fp32 values and vectors"), launches=int(agg["spmv_launches"]),
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     empty_event_pair_us=1e3 * agg.get("ev_over", 0.0),
-                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_c_pmc_traffic_default_bench.json")
+                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if args.precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_c_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f64", data="synthetic",
+               dtype="f64" if args.precision == "fp64" else "f32 PCG inside f64 residual refinement", data="synthetic",
                config=dict(workload=f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
                            batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
                            mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, preconditioner="multigrid = Chebyshev(6) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
+                           maxsteps=args.maxsteps, precision=args.precision, preconditioner="multigrid = Chebyshev(6) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
                            batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline,
                breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 1
+#define REMO_ABI_VERSION 2
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -63,7 +63,10 @@ typedef struct {
     int32_t time_kernels;   /* 1 = bracket every SpMV launch with HIP events (bench roofline)      */
     int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default 6) */
     int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default 15) */
-    int32_t reserved[3];
+    int32_t precision;      /* 0 = fp64 throughout; 1 = mixed (BASELINE config 5): PCG in fp32 storage inside an fp64
+                               residual-refinement loop, stopping test on the true fp64 residual           */
+    int32_t inner_digits;   /* mixed: decimal digits gained per inner solve before the residual is refreshed (0 => 4) */
+    int32_t reserved[1];
 } remo_opts_t;
 
 typedef struct {
@@ -89,6 +92,7 @@ typedef struct {
     double spmv_ms_raw;  /* the same sum before the correction                                     */
     double event_overhead_ms; /* elapsed time of an EMPTY hipEvent pair on the stream (min of 16),
                             i.e. what a bracket measures beyond the kernel it encloses             */
+    int64_t refinement_cycles; /* mixed precision: fp32 inner solves that contributed a correction (all chunks) */
 } remo_stats_t;
 
 typedef struct remo_ctx remo_ctx_t;

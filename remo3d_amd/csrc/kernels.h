@@ -16,33 +16,38 @@ struct PcgProgress {
     int32_t pad;
 };
 
-struct PcgBuffers {
-    double *x, *r, *p, *q;  // [n*k]
-    const double *dinv;     // [n]
+// T = storage type of matrix values and vectors: double (product path) or float (inner solver of the
+// mixed-precision mode); scalars and partial sums are double in both
+template <class T> struct PcgBuffersT {
+    T *x, *r, *p, *q;       // [n*k]
+    const T *dinv;          // [n]
     double *part_pq;        // [kMaxPartialBlocks*8] per-workgroup partial sums of <p, Ap>
     double *part_rz;        // [2][kMaxPartialBlocks*8] per-workgroup partial sums of <Cr, r> (even / odd step)
-    double *rz0;            // [40] totals forwarded between launches: <Cr0,r0>[8] | <p,Ap>[8] | <Cr,r> of even / odd steps [8+8] | done flag
+    double *rz0;            // [48] totals forwarded between launches: <Cr0,r0>[8] | <p,Ap>[8] | <Cr,r> of even / odd steps [8+8] | done flag [8] | floor of <Cr,r> [8]
     // two-level preconditioner (vertex-block Chebyshev); cheb_degree = 0 -> Jacobi
     int64_t nv_coarse;      // free vertex dofs = size of the leading P1 block
     int cheb_degree;
     double cheb_lmax, cheb_lmin;
-    double *cz, *cres;      // [nv_coarse*k]
-    double *cd[2];          // [nv_coarse*k] ping-pong Chebyshev directions
+    T *cz, *cres;           // [nv_coarse*k]
+    T *cd[2];               // [nv_coarse*k] ping-pong Chebyshev directions
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
 };
+using PcgBuffers = PcgBuffersT<double>;
+constexpr int kScalarSlots = 48;   // doubles behind PcgBuffersT::rz0
 
-struct CsrView {
+template <class T> struct CsrViewT {
     int64_t n;
     int64_t nnz;
     const int32_t *rowptr;
     const int32_t *col;
-    const double *val;
+    const T *val;
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
     // column patterns (0, 0 = unknown)
     int64_t pair_begin = 0, pair_end = 0;
 };
+using CsrView = CsrViewT<double>;
 
 void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,
                          const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s);
@@ -55,14 +60,19 @@ int vec_grid(int64_t n);
 void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 threads, 3 mapping, 4 grid (0 = default)
 int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
-void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, const double *scal, int nblocks, hipStream_t s);
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s);
 
-void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers &b, hipStream_t s);       // + C r0, p0
-void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);  // + C r (Chebyshev steps)
-void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s);
+template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
+template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);
+template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s);
 void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s);
 int cheb_grid(int64_t nv);
-void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s);
+
+// mixed precision: conversions around the fp32 inner solve
+void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s);
+void launch_mixed_residual(int64_t n, const double *f, const double *q /* may be null */, float *r32, hipStream_t s);
+void launch_mixed_accumulate(int64_t n, double *x, const float *e, hipStream_t s);
 
 // point location on the borehole axis + shape values; found[] must be pre-set to INT_MAX
 void launch_locate(int dim, int64_t nt, const double *coords, const int32_t *conn, int npts, const double *pz,

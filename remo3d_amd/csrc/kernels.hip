@@ -21,7 +21,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int W> __device__ __forceinline__ double group_sum(double v) {
+template <int W, class T> __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
     for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -41,8 +41,11 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 // value of the partner lane in the other half of the W-lane group (a bijection between the halves)
-template <int W> __device__ __forceinline__ double partner(double v) {
+template <int W, class T> __device__ __forceinline__ T partner(T v) {
     if constexpr (W == 16) return dpp_mov<0x140>(v);      // row_mirror: i <-> 15 - i
     else if constexpr (W == 8) return dpp_mov<0x141>(v);  // row_half_mirror: i <-> 7 - i
     else if constexpr (W == 4) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -53,18 +56,18 @@ constexpr int treduce_out(int m, int w) { return w < 2 ? m : treduce_out((m + 1)
 // In place: on return v[0 .. treduce_out(M, W)) are complete group sums; which ones, per lane, is
 // given by TOwner below (same recursion on indices).  Fixed order: deterministic.
 template <int M, int W> struct TReduce {
-    static __device__ __forceinline__ void run(double *v, int sub) {
+    template <class T> static __device__ __forceinline__ void run(T *v, int sub) {
         if constexpr (W >= 2) {
             const bool hi = (sub & (W / 2)) != 0;
             constexpr int P = M / 2;
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-                const double a = v[2 * j], b = v[2 * j + 1];
-                v[j] = (hi ? b : a) + partner<W>(hi ? a : b);
+                const T a = v[2 * j], b = v[2 * j + 1];
+                v[j] = (hi ? b : a) + partner<W, T>(hi ? a : b);
             }
             if constexpr (M & 1) {
-                const double l = v[M - 1];
-                v[P] = l + partner<W>(l);
+                const T l = v[M - 1];
+                v[P] = l + partner<W, T>(l);
             }
             TReduce<(M + 1) / 2, W / 2>::run(v, sub);
         }
@@ -278,71 +281,28 @@ void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowpt
 // LPR partial sums are combined with wave shuffles.  Optionally leaves per-block partial sums of
 // <x, y> (the CG's <p, Ap>) so the dot product costs no extra pass.
 
-// first row r in [0, n] with rowptr[r] >= target
-__device__ __forceinline__ int64_t row_of_offset(const int32_t *__restrict__ rowptr, int64_t n, int64_t target) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// Row walk shared by the SpMM variants.  mapping 0: plain grid-stride over row groups.
-// mapping 1 (XCD-aware, speed only): workgroups b and b + 8 share an XCD and its 4 MiB L2, so
-// each residue class mod 8 walks one contiguous, nnz-balanced row range and the x rows it gathers
-// stay within one slice of each entity block.
-struct RowWalk {
-    int64_t begin, end, step;
-};
-__device__ __forceinline__ RowWalk row_walk(int mapping, int64_t n, int64_t nnz, const int32_t *__restrict__ rowptr, int rpb, int grp) {
-    RowWalk w;
-    if (mapping == 0) {
-        w.begin = int64_t(blockIdx.x) * rpb + grp;
-        w.end = n;
-        w.step = int64_t(gridDim.x) * rpb;
-    } else if (mapping == 1) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-        const int64_t r0 = row_of_offset(rowptr, n, (nnz * xcd) >> 3);
-        w.end = (xcd == 7) ? n : row_of_offset(rowptr, n, (nnz * (xcd + 1)) >> 3);
-        w.begin = r0 + int64_t(slot) * rpb + grp;
-        w.step = int64_t(per_xcd) * rpb;
-    } else {
-        // mapping 2/3: every workgroup walks ONE contiguous, nnz-balanced row range front to back, so
-        // the x rows gathered by consecutive passes overlap and stay in the CU's L1; with mapping 3
-        // the ranges of one XCD (workgroups b, b + 8, ...) are also adjacent to each other.
-        const int nb = gridDim.x;
-        const int chunk = (mapping == 3) ? ((blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
-        const int64_t r0 = row_of_offset(rowptr, n, (nnz * chunk) / nb);
-        w.end = (chunk == nb - 1) ? n : row_of_offset(rowptr, n, (nnz * (chunk + 1)) / nb);
-        w.begin = r0 + grp;
-        w.step = rpb;
-    }
-    return w;
-}
-
-// Variant A ("lane per nonzero"): every lane owns one stored entry and all K columns of it; the x
-// row is gathered with K 8-byte loads.
-template <int K, int LPR, bool DOT>
-__global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mapping, const int32_t *__restrict__ rowptr,
-                                              const int32_t *__restrict__ col, const double *__restrict__ val,
-                                              const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
+// Variant A ("lane per stored entry"): the fallback for matrices without edge-row pairs and the
+// baseline of tools/probe_spmm.py.  T = double (the product path) or float (inner solver of the
+// mixed-precision mode); dot-product partials are always accumulated in double.
+template <class T, int K, int LPR, bool DOT>
+__global__ void __launch_bounds__(512) k_spmm(int64_t n, const int32_t *__restrict__ rowptr,
+                                              const int32_t *__restrict__ col, const T *__restrict__ val,
+                                              const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
     if (scal && solve_done(scal)) return;
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
-    const RowWalk w = row_walk(mapping, n, nnz, rowptr, rpb, grp);
     double dot[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) dot[c] = 0.0;
-    for (int64_t row = w.begin; row < w.end; row += w.step) {
+    for (int64_t row = int64_t(blockIdx.x) * rpb + grp; row < n; row += int64_t(gridDim.x) * rpb) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
-        double acc[K];
+        T acc[K];
 #pragma unroll
-        for (int c = 0; c < K; ++c) acc[c] = 0.0;
+        for (int c = 0; c < K; ++c) acc[c] = T(0);
         for (int32_t p = rs + sub; p < re; p += LPR) {
-            const double v = val[p];
-            const double *xr = x + int64_t(col[p]) * K;
+            const T v = val[p];
+            const T *xr = x + int64_t(col[p]) * K;
 #pragma unroll
             for (int c = 0; c < K; ++c) acc[c] += v * xr[c];
         }
@@ -352,9 +312,9 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mappin
 #pragma unroll
             for (int c = 0; c < K; ++c) y[row * K + c] = acc[c];
             if (DOT) {
-                const double *xr = x + row * K;
+                const T *xr = x + row * K;
 #pragma unroll
-                for (int c = 0; c < K; ++c) dot[c] += acc[c] * xr[c];
+                for (int c = 0; c < K; ++c) dot[c] += double(acc[c]) * double(xr[c]);
             }
         }
     }
@@ -374,10 +334,10 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t nnz, int mappin
 // passes of its row up front and then all U gathers, before any arithmetic: a row of <= U * LPR
 // entries pays the two latencies once instead of once per pass.  Lanes past the row end read a
 // safe address with a zero value (no branches between the loads).
-template <int K, int LPR, bool DOT, int MODE = 0>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
+template <class T, int K, int LPR, bool DOT, int MODE = 0>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
 __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, int xcd_windows, const int32_t *__restrict__ rowptr,
-                                                   const int32_t *__restrict__ col, const double *__restrict__ val,
-                                                   const double *__restrict__ x, double *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
+                                                   const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                   const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
     if (scal && solve_done(scal)) return;
     constexpr int U = 2;
     constexpr int MFP = treduce_out(2 * K, LPR), MFS = treduce_out(K, LPR);   // sums per lane after the reduction
@@ -427,16 +387,16 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
             re_n = rowptr[row_n + 1];
         }
         const int32_t len = pair ? re - rs : 0;   // the second row's values sit `len` entries further
-        double acc[2 * K];                        // [0, K): row, [K, 2K): row + 1
+        T acc[2 * K];                             // [0, K): row, [K, 2K): row + 1
 #pragma unroll
-        for (int c = 0; c < 2 * K; ++c) acc[c] = 0.0;
+        for (int c = 0; c < 2 * K; ++c) acc[c] = T(0);
         for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {
             int32_t j[U];
-            double v0[U], v1[U], xv[U][K];
+            T v0[U], v1[U], xv[U][K];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int32_t p = p0 + u * LPR;
-                j[u] = -1; v0[u] = 0.0; v1[u] = 0.0;
+                j[u] = -1; v0[u] = T(0); v1[u] = T(0);
                 if (p < re) {                        // lanes past the row end issue nothing (exec-masked loads)
                     j[u] = col[p];
                     v0[u] = val[p];
@@ -446,13 +406,13 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int c = 0; c < K; ++c) xv[u][c] = 0.0;
+                for (int c = 0; c < K; ++c) xv[u][c] = T(0);
                 if (j[u] >= 0) {
                     if (MODE == 1) {          // no gather at all
 #pragma unroll
-                        for (int c = 0; c < K; ++c) xv[u][c] = double(j[u]);
+                        for (int c = 0; c < K; ++c) xv[u][c] = T(j[u]);
                     } else {
-                        const double *xr = x + int64_t(MODE == 2 ? (j[u] & 255) : j[u]) * K;   // 2: L1-resident gather
+                        const T *xr = x + int64_t(MODE == 2 ? (j[u] & 255) : j[u]) * K;   // 2: L1-resident gather
 #pragma unroll
                         for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
                     }
@@ -467,10 +427,10 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
                 }
         }
         if (MODE == 3) {   // no reduction, (practically) no store
-            double t = 0.0;
+            T t = T(0);
 #pragma unroll
             for (int c = 0; c < 2 * K; ++c) t += acc[c];
-            if (t == 1.2345e300) y[row * K] = t;
+            if (t == T(1.2345e30)) y[row * K] = t;
             continue;
         }
         // wave-uniform choice (row classes are contiguous, so all but a handful of waves are uniform)
@@ -481,7 +441,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
                 if (own_p[f] && (pair || idx_p[f] < K)) {
                     const int64_t at = row * K + idx_p[f];
                     y[at] = acc[f];
-                    if (DOT) dot_p[f] += acc[f] * x[at];
+                    if (DOT) dot_p[f] += double(acc[f]) * double(x[at]);
                 }
         } else {
             TReduce<K, LPR>::run(acc, sub);
@@ -490,7 +450,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
                 if (own_s[f]) {
                     const int64_t at = row * K + idx_s[f];
                     y[at] = acc[f];
-                    if (DOT) dot_s[f] += acc[f] * x[at];
+                    if (DOT) dot_s[f] += double(acc[f]) * double(x[at]);
                 }
         }
     }
@@ -552,28 +512,28 @@ int spmv_grid(int64_t n, int lpr) {
     return int(g);
 }
 
-template <int K> static void spmm_dispatch(const CsrView &A, const double *x, double *y, double *part, const double *scal, int nb, hipStream_t s) {
+template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s) {
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
     int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
-    // default row mapping: XCD windows for the pair kernel (measured 69 -> 60 us at 329k rows, k = 5), plain grid-stride otherwise
-    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : (variant == 3 ? 1 : 0);
-#define REMO_SPMM(KERNEL, L)                                                                                                          \
-    if (part)                                                                                                                         \
-        hipLaunchKernelGGL((KERNEL<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
-    else                                                                                                                              \
-        hipLaunchKernelGGL((KERNEL<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.nnz, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
+    // default row mapping of the pair kernel: XCD windows (measured 69 -> 60 us at 329k rows, k = 5)
+    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 1;
+#define REMO_SPMM(L)                                                                                                        \
+    if (part)                                                                                                               \
+        hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part, scal); \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part, scal)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
-    if constexpr (K == 5) {
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
+    if constexpr (K == 5 && sizeof(T) == 8) {   // ablation modes of tools/probe_ablate.py
         if (variant == 3 && lpr == 16 && g_tune.mode >= 1 && g_tune.mode <= 3 && !part) {
-            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
-            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
-            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
             return;
         }
     }
@@ -583,27 +543,29 @@ template <int K> static void spmm_dispatch(const CsrView &A, const double *x, do
         else if (lpr == 8) { REMO_SPMM_PAIR(8); }
         else { REMO_SPMM_PAIR(4); }
     } else {
-        if (lpr >= 32) { REMO_SPMM(k_spmm, 32); }
-        else if (lpr == 16) { REMO_SPMM(k_spmm, 16); }
-        else if (lpr == 8) { REMO_SPMM(k_spmm, 8); }
-        else { REMO_SPMM(k_spmm, 4); }
+        if (lpr >= 32) { REMO_SPMM(32); }
+        else if (lpr == 16) { REMO_SPMM(16); }
+        else if (lpr == 8) { REMO_SPMM(8); }
+        else { REMO_SPMM(4); }
     }
 #undef REMO_SPMM
 #undef REMO_SPMM_PAIR
 }
 
-void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *part, const double *scal, int nb, hipStream_t s) {
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s) {
     switch (k) {
-        case 1: spmm_dispatch<1>(A, x, y, part, scal, nb, s); break;
-        case 2: spmm_dispatch<2>(A, x, y, part, scal, nb, s); break;
-        case 3: spmm_dispatch<3>(A, x, y, part, scal, nb, s); break;
-        case 4: spmm_dispatch<4>(A, x, y, part, scal, nb, s); break;
-        case 5: spmm_dispatch<5>(A, x, y, part, scal, nb, s); break;
-        case 6: spmm_dispatch<6>(A, x, y, part, scal, nb, s); break;
-        case 7: spmm_dispatch<7>(A, x, y, part, scal, nb, s); break;
-        default: spmm_dispatch<8>(A, x, y, part, scal, nb, s); break;
+        case 1: spmm_dispatch<T, 1>(A, x, y, part, scal, nb, s); break;
+        case 2: spmm_dispatch<T, 2>(A, x, y, part, scal, nb, s); break;
+        case 3: spmm_dispatch<T, 3>(A, x, y, part, scal, nb, s); break;
+        case 4: spmm_dispatch<T, 4>(A, x, y, part, scal, nb, s); break;
+        case 5: spmm_dispatch<T, 5>(A, x, y, part, scal, nb, s); break;
+        case 6: spmm_dispatch<T, 6>(A, x, y, part, scal, nb, s); break;
+        case 7: spmm_dispatch<T, 7>(A, x, y, part, scal, nb, s); break;
+        default: spmm_dispatch<T, 8>(A, x, y, part, scal, nb, s); break;
     }
 }
+template void launch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t);
+template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Jacobi-PCG vector kernels (CGSolver(a.mat, c.mat), ngsolve_functions.py:50-51), K columns at
@@ -624,45 +586,51 @@ void launch_spmm(const CsrView &A, int k, const double *x, double *y, double *pa
 // the Jacobi-scaled vertex block (spectrum bounds [lmax/ratio, lmax], lmax = Gershgorin bound, so
 // q_d is positive definite on the whole spectrum and plain PCG stays valid) and Jacobi on edge/face
 // dofs.  nv = 0 gives plain Jacobi ("local").
-struct ChebArgs {
+template <class T> struct ChebArgsT {
     int64_t nv;       // free vertex dofs (0: Jacobi)
     double inv_theta; // 1 / theta, theta = (lmax + lmin) / 2
-    double *z, *res;  // [nv][K] polynomial value so far / residual of the vertex block system
-    double *d0;       // [nv][K] first Chebyshev direction
+    T *z, *res;       // [nv][K] polynomial value so far / residual of the vertex block system
+    T *d0;            // [nv][K] first Chebyshev direction
 };
+// All PCG kernels are templates on the storage type T of matrix values and vectors: double = the
+// product path, float = the inner solver of the mixed-precision mode (BASELINE config 5).  Scalars,
+// partial sums and the convergence test are double in both.
+// scal[kFloorSlot + c]: absolute floor of <Cr,r> below which column c is frozen as well (0 in the plain
+// fp64 solve; the outer target of the refinement in the mixed mode)
+constexpr int kFloorSlot = 5 * 8;
 
-template <int K>
-__global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgs ch, const double *__restrict__ f, const double *__restrict__ dinv,
-                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgsT<T> ch, const T *__restrict__ f, const T *__restrict__ dinv,
+                                                  T *__restrict__ x, T *__restrict__ r, T *__restrict__ p,
                                                   double *__restrict__ part_rz) {
     __shared__ double smem[16 * K];
     double rz[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) rz[c] = 0.0;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const double d = dinv[i];
+        const T d = dinv[i];
         const bool coarse = i < ch.nv;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            const double ri = f[i * K + c];
-            const double zi = d * ri;
-            x[i * K + c] = 0.0;
+            const T ri = f[i * K + c];
+            const T zi = d * ri;
+            x[i * K + c] = T(0);
             r[i * K + c] = ri;
-            p[i * K + c] = coarse ? 0.0 : zi;
-            rz[c] += coarse ? 0.0 : ri * zi;   // the vertex block's share comes from the Chebyshev kernels
+            p[i * K + c] = coarse ? T(0) : zi;
+            rz[c] += coarse ? 0.0 : double(ri) * double(zi);   // the vertex block's share comes from the Chebyshev kernels
         }
     }
     block_sum<K>(rz, smem);
     if (threadIdx.x < K) part_rz[blockIdx.x * K + threadIdx.x] = rz[threadIdx.x];
 }
 
-template <int K>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int nb_spmv, int nb_rz, ChebArgs ch,
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int nb_spmv, int nb_rz, ChebArgsT<T> ch,
                                                     const double *__restrict__ part_pq, const double *__restrict__ part_rz_cur,
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
-                                                    PcgProgress *progress, int progress_len, const double *__restrict__ p,
-                                                    const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
-                                                    const double *__restrict__ dinv) {
+                                                    PcgProgress *progress, int progress_len, const T *__restrict__ p,
+                                                    const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
+                                                    const T *__restrict__ dinv) {
     // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
@@ -679,7 +647,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         const double r0 = (step == 0) ? rz[c] : rz0[c];
-        const bool live = (rz[c] > tol2 * r0) && (pq[c] > 0.0);
+        const bool live = (rz[c] > tol2 * r0) && (rz[c] > scal[kFloorSlot + c]) && (pq[c] > 0.0);
         alpha[c] = live ? rz[c] / pq[c] : 0.0;
         acc[c] = 0.0;
     }
@@ -706,16 +674,16 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const double d = dinv[i];
+        const T d = dinv[i];
         const bool coarse = i < ch.nv;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            const double a = alpha[c];
-            const double xi = x[i * K + c] + a * p[i * K + c];
-            const double ri = r[i * K + c] - a * q[i * K + c];
+            const T a = T(alpha[c]);
+            const T xi = x[i * K + c] + a * p[i * K + c];
+            const T ri = r[i * K + c] - a * q[i * K + c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
-            acc[c] += coarse ? 0.0 : ri * ri * d;   // the vertex block's share comes from the Chebyshev kernels
+            acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels
         }
     }
     __syncthreads();
@@ -727,12 +695,13 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 //   z += d;  res -= A_vv d;  d' = c1 d + c2 D^-1 res
 // FIRST: z = 0, res = r, d = D^-1 r / theta are formed on the fly from the PCG residual (no set-up
 // pass); LAST: d' is skipped and the <r, z> partial sums are left for the PCG scalars.
-template <int K, bool FIRST, bool LAST>
+template <class T, int K, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const double *__restrict__ val, const double *__restrict__ dinv,
-                                                   const double *__restrict__ d_old, double *__restrict__ d_new,
-                                                   double *__restrict__ z, double *__restrict__ res, double c1, double c2, double inv_theta,
-                                                   const double *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
+                                                   const T *__restrict__ val, const T *__restrict__ dinv,
+                                                   const T *__restrict__ d_old, T *__restrict__ d_new,
+                                                   T *__restrict__ z, T *__restrict__ res, double c1_, double c2_, double inv_theta_,
+                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
+    const T c1 = T(c1_), c2 = T(c2_), inv_theta = T(inv_theta_);
     constexpr int LPR = 8, RPB = 256 / LPR;
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
     if (solve_done(scal)) return;
@@ -748,34 +717,34 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
     for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
         const int64_t at = row * K + mycol;
-        double di = 0.0, rr = 0.0, dold_in = 0.0, z_in = 0.0, res_in = 0.0;
+        T di = T(0), rr = T(0), dold_in = T(0), z_in = T(0), res_in = T(0);
         if (mine) {
             di = dinv[row];
             rr = r[at];
             if (!FIRST) { dold_in = d_old[at]; z_in = z[at]; res_in = res[at]; }
         }
-        double t[K];
+        T t[K];
 #pragma unroll
-        for (int c = 0; c < K; ++c) t[c] = 0.0;
+        for (int c = 0; c < K; ++c) t[c] = T(0);
         for (int32_t p = rs + sub; p < re; p += LPR) {
             const int32_t j = col[p];
             if (j >= nv) break;  // columns ascend: the vertex block leads the row
-            const double v = FIRST ? val[p] * dinv[j] * inv_theta : val[p];
-            const double *dj = (FIRST ? r : d_old) + int64_t(j) * K;
+            const T v = FIRST ? val[p] * dinv[j] * inv_theta : val[p];
+            const T *dj = (FIRST ? r : d_old) + int64_t(j) * K;
 #pragma unroll
             for (int c = 0; c < K; ++c) t[c] += v * dj[c];
         }
         TReduce<K, LPR>::run(t, sub);
         if (mine) {
-            const double dold = FIRST ? di * rr * inv_theta : dold_in;
-            const double zi = FIRST ? dold : z_in + dold;
-            const double ri = (FIRST ? rr : res_in) - t[0];
+            const T dold = FIRST ? di * rr * inv_theta : dold_in;
+            const T zi = FIRST ? dold : z_in + dold;
+            const T ri = (FIRST ? rr : res_in) - t[0];
             z[at] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
             if (!LAST) {
                 res[at] = ri;
                 d_new[at] = c1 * dold + c2 * di * ri;
             }
-            if (LAST) dot += rr * zi;
+            if (LAST) dot += double(rr) * double(zi);
         }
     }
     if (LAST) {
@@ -790,11 +759,11 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
     }
 }
 
-template <int K>
-__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgs ch,
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgsT<T> ch,
                                                        const double *__restrict__ part_rz_new, double *__restrict__ scal,
-                                                       const double *__restrict__ r, double *__restrict__ p,
-                                                       const double *__restrict__ dinv) {
+                                                       const T *__restrict__ r, T *__restrict__ p,
+                                                       const T *__restrict__ dinv) {
     __shared__ double smem[16 * K];
     if (solve_done(scal)) return;
     double beta[K];
@@ -807,7 +776,7 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const double pq = scal[8 + c], rzo = scal[16 + 8 * (step & 1) + c];   // forwarded by the update launch
-            const bool live = (rzo > tol2 * scal[c]) && (pq > 0.0);
+            const bool live = (rzo > tol2 * scal[c]) && (rzo > scal[kFloorSlot + c]) && (pq > 0.0);
             beta[c] = live ? rzn[c] / rzo : 0.0;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -815,12 +784,12 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
             for (int c = 0; c < K; ++c) scal[16 + 8 * ((step + 1) & 1) + c] = rzn[c];   // read by the next update launch
     }
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const double d = dinv[i];
-        const double *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
+        const T d = dinv[i];
+        const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            const double zi = d * src[i * K + c];
-            p[i * K + c] = first ? zi : zi + beta[c] * p[i * K + c];
+            const T zi = d * src[i * K + c];
+            p[i * K + c] = first ? zi : zi + T(beta[c]) * p[i * K + c];
         }
     }
 }
@@ -891,8 +860,8 @@ int cheb_grid(int64_t nv) {
         default: { constexpr int KK = 8; CALL; } break; \
     }
 
-static ChebArgs cheb_args(const PcgBuffers &b) {
-    ChebArgs c;
+template <class T> static ChebArgsT<T> cheb_args(const PcgBuffersT<T> &b) {
+    ChebArgsT<T> c;
     c.nv = b.cheb_degree > 0 ? b.nv_coarse : 0;
     c.inv_theta = b.cheb_degree > 0 ? 1.0 / (0.5 * (b.cheb_lmax + b.cheb_lmin)) : 0.0;
     c.z = b.cz; c.res = b.cres; c.d0 = b.cd[0];
@@ -901,7 +870,7 @@ static ChebArgs cheb_args(const PcgBuffers &b) {
 
 // C r for the vertex block: `degree` Chebyshev steps; the last one leaves the <r_v, z_v> partials
 // behind the nb_vec partials of the high-order part (slot = even / odd step buffer)
-static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *part_slot, hipStream_t s) {
+template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
     const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
     const double sig = theta / delta, inv_theta = 1.0 / theta;
@@ -912,11 +881,11 @@ static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *pa
         const double rho_new = 1.0 / (2.0 * sig - rho);
         const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
         rho = rho_new;
-        const double *dold = b.cd[j & 1];
-        double *dnew = b.cd[(j + 1) & 1];
+        const T *dold = b.cd[j & 1];
+        T *dnew = b.cd[(j + 1) & 1];
         const bool first = (j == 0), last = (j + 1 == b.cheb_degree);
-#define REMO_CHEB(F, L)                                                                                                                          \
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
+#define REMO_CHEB(F, L)                                                                                                                             \
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
                                         b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0))
         if (first && last) { REMO_CHEB(true, true); }
         else if (first) { REMO_CHEB(true, false); }
@@ -926,40 +895,80 @@ static void launch_cheb(const CsrView &A, int k, const PcgBuffers &b, double *pa
     }
 }
 
-static int nb_rz(const PcgBuffers &b) { return b.nb_vec + ((b.cheb_degree > 0 && b.nv_coarse > 0) ? cheb_grid(b.nv_coarse) : 0); }
+template <class T> static int nb_rz(const PcgBuffersT<T> &b) { return b.nb_vec + ((b.cheb_degree > 0 && b.nv_coarse > 0) ? cheb_grid(b.nv_coarse) : 0); }
 
-void launch_pcg_init(const CsrView &A, int k, const double *f, const PcgBuffers &b, hipStream_t s) {
+template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
-    const ChebArgs ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_init<KK>, dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
+    const ChebArgsT<T> ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_init<T, KK>), dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
     launch_cheb(A, k, b, b.part_rz, s);
     if (ch.nv > 0)
-        REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv));
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv));
 }
 
-void launch_pcg_update(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
+template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
-    const ChebArgs ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_update<KK>, dim3(g), dim3(256), 0, s, n, step, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+    const ChebArgsT<T> ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
     launch_cheb(A, k, b, nxt, s);
 }
 
-void launch_pcg_direction(const CsrView &A, int k, int step, double tol2, const PcgBuffers &b, hipStream_t s) {
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
-    const ChebArgs ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_direction<KK>, dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv));
+    const ChebArgsT<T> ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv));
 }
 
-void launch_pcg_final(int k, int step, const PcgBuffers &b, hipStream_t s) {
+template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s) {
     const double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     REMO_K_SWITCH(k, hipLaunchKernelGGL(k_pcg_final<KK>, dim3(1), dim3(256), 0, s, step, nb_rz(b), cur, b.rz0, b.progress, b.progress_len));
+}
+
+#define REMO_INSTANTIATE_PCG(T)                                                                                          \
+    template void launch_pcg_init<T>(const CsrViewT<T> &, int, const T *, const PcgBuffersT<T> &, hipStream_t);          \
+    template void launch_pcg_update<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);      \
+    template void launch_pcg_direction<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);   \
+    template void launch_pcg_final<T>(int, int, const PcgBuffersT<T> &, hipStream_t);
+REMO_INSTANTIATE_PCG(double)
+REMO_INSTANTIATE_PCG(float)
+#undef REMO_INSTANTIATE_PCG
+
+// ------------------------------------------------------------------------------------------
+// mixed precision (BASELINE config 5): fp32 inner PCG, fp64 residual refinement.  The outer loop is
+//   r = f - A x (fp64 SpMM)  ->  r32 = (float) r  ->  inner PCG on A32 e = r32  ->  x += e
+
+__global__ void __launch_bounds__(256) k_to_float(int64_t n, const double *__restrict__ src, float *__restrict__ dst) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) dst[i] = float(src[i]);
+}
+// r32 = float(f - q)   (q = nullptr: x = 0, r = f)
+__global__ void __launch_bounds__(256) k_mixed_residual(int64_t n, const double *__restrict__ f, const double *__restrict__ q, float *__restrict__ r32) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+        r32[i] = float(q ? f[i] - q[i] : f[i]);
+}
+// x += e
+__global__ void __launch_bounds__(256) k_mixed_accumulate(int64_t n, double *__restrict__ x, const float *__restrict__ e) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) x[i] += double(e[i]);
+}
+static int stream_grid(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    return int(g < 1 ? 1 : g);
+}
+void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_to_float, dim3(stream_grid(n)), dim3(256), 0, s, n, src, dst);
+}
+void launch_mixed_residual(int64_t n, const double *f, const double *q, float *r32, hipStream_t s) {
+    hipLaunchKernelGGL(k_mixed_residual, dim3(stream_grid(n)), dim3(256), 0, s, n, f, q, r32);
+}
+void launch_mixed_accumulate(int64_t n, double *x, const float *e, hipStream_t s) {
+    hipLaunchKernelGGL(k_mixed_accumulate, dim3(stream_grid(n)), dim3(256), 0, s, n, x, e);
 }
 
 // ------------------------------------------------------------------------------------------

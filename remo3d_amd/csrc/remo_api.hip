@@ -61,6 +61,7 @@ struct remo_ctx {
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> spmv_ev;
     uint64_t run_id = 0;  // the arena holds the system / solution of the batch that ran last
+    double floor_stage[REMO_MAX_RHS] = {};   // host staging of the mixed mode's <Cr,r> floors (outlives the async copy)
 
     template <class T> T *take(size_t count) { return ar.lo<T>(count); }
     void reserve(size_t bytes) {
@@ -124,28 +125,34 @@ struct ChunkResult {
     double relres[REMO_MAX_RHS];
 };
 
-ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, PcgBuffers &buf, const remo_opts_t &o,
-                    remo_stats_t *st, size_t &ev_used) {
+// One PCG solve in storage type T.  tol2: relative target on <Cr,r> (w.r.t. this solve's own start);
+// floor: optional absolute per-column floor of <Cr,r> (mixed mode: the outer target).  rz_first /
+// rz_last return <Cr,r> at the start and at the end.
+template <class T>
+ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, PcgBuffersT<T> &buf, double tol2, const double *floor,
+                      int maxit, int check, bool time_kernels, remo_stats_t *st, size_t &ev_used, double *rz_first, double *rz_last) {
     ChunkResult res;
     hipStream_t s = ctx->stream;
-    const double tol2 = o.rtol * o.rtol;
-    const int maxit = o.maxsteps;
-    const int check = o.check_every > 0 ? o.check_every : 10;
+    if (check <= 0) check = 10;
     for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
-    HIP_TRY(hipMemsetAsync(buf.rz0, 0, 40 * sizeof(double), s));   // forwarded totals + done flag
+    HIP_TRY(hipMemsetAsync(buf.rz0, 0, kScalarSlots * sizeof(double), s));   // forwarded totals + done flag + floor
+    if (floor) {
+        std::memcpy(ctx->floor_stage, floor, sizeof(double) * REMO_MAX_RHS);
+        HIP_TRY(hipMemcpyAsync(buf.rz0 + 5 * 8, ctx->floor_stage, sizeof(double) * REMO_MAX_RHS, hipMemcpyHostToDevice, s));
+    }
     launch_pcg_init(A, k, d_f, buf, s);
     volatile int32_t *done_step = &ctx->progress[ctx->progress_len - 1].step;
     int step = 0;
     bool done = false;
     for (; step < maxit && !done;) {
-        if (o.time_kernels && ev_used + 2 <= ctx->spmv_ev.size()) {
+        if (time_kernels && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
-            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.rz0, buf.nb_spmv, s);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
             ev_used += 2;
         } else {
-            launch_spmm(A, k, buf.p, buf.q, buf.part_pq, buf.rz0, buf.nb_spmv, s);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
         }
         launch_pcg_update(A, k, step, tol2, buf, s);
         launch_pcg_direction(A, k, step, tol2, buf, s);
@@ -183,24 +190,90 @@ ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, P
     const int last = (dn.step >= 0) ? dn.step : step;   // index of the record that holds the final <Cr,r>
     const PcgProgress &fin = (dn.step >= 0) ? dn : ctx->progress[step % (ctx->progress_len - 1)];
     res.steps = (dn.step >= 0) ? dn.step : step;
-    const PcgProgress &p0 = ctx->progress[0];
+    const PcgProgress &p0 = (last == 0) ? fin : ctx->progress[0];
     res.converged = true;
     for (int c = 0; c < k; ++c) {
         res.iters[c] = last;
         const double r0 = p0.rz[c];
+        const double thr = std::max(tol2 * r0, floor ? floor[c] : 0.0);
         for (int i = 0; i <= last; ++i) {
             const PcgProgress &pr = (i == last) ? fin : ctx->progress[i % (ctx->progress_len - 1)];
             if (i != last && pr.step != i) continue;
             if (!std::isfinite(pr.rz[c])) res.finite = false;
-            if (!(pr.rz[c] > tol2 * r0)) { res.iters[c] = i; break; }
+            if (!(pr.rz[c] > thr)) { res.iters[c] = i; break; }
         }
         const double rl = fin.rz[c];
         res.relres[c] = (r0 > 0.0) ? std::sqrt(rl / r0) : 0.0;
-        if (rl > tol2 * r0) res.converged = false;
+        if (rl > thr) res.converged = false;
         if (!std::isfinite(rl)) res.finite = false;
+        if (rz_first) rz_first[c] = r0;
+        if (rz_last) rz_last[c] = rl;
     }
     if (st) st->pcg_steps += res.steps;
     return res;
+}
+
+ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, PcgBuffers &buf, const remo_opts_t &o,
+                    remo_stats_t *st, size_t &ev_used) {
+    return run_pcg_t<double>(ctx, A, k, d_f, buf, o.rtol * o.rtol, nullptr, o.maxsteps, o.check_every, o.time_kernels != 0, st, ev_used, nullptr,
+                             nullptr);
+}
+
+// Mixed precision (BASELINE config 5): the fp64 system A x = f is solved by iterative refinement
+// whose corrections come from PCG in fp32 storage (matrix values, vectors, preconditioner); scalars and
+// the stopping test stay fp64.  Cycle: r = f - A x in fp64 -> e = PCG32(A32, r) to `digits` decimal
+// digits or down to the outer target, whichever comes first -> x += e.  A solve ends with a cycle
+// whose START already meets the target, i.e. the criterion is checked on the TRUE fp64 residual,
+// not on a recurrence.  <Cr,r> of the refinement is measured with the fp32 preconditioner.
+struct MixedBuffers {
+    CsrViewT<float> A32{};
+    PcgBuffersT<float> b32{};
+    float *f32 = nullptr;
+};
+
+ChunkResult run_pcg_mixed(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, PcgBuffers &buf, MixedBuffers &mx, const remo_opts_t &o,
+                          remo_stats_t *st, size_t &ev_used) {
+    hipStream_t s = ctx->stream;
+    const int64_t nk = A.n * k;
+    const double tol2 = o.rtol * o.rtol;
+    const int digits = o.inner_digits > 0 ? o.inner_digits : 4;
+    const double tol2_in = std::pow(10.0, -2.0 * digits);
+    ChunkResult out;
+    out.converged = false;
+    for (int c = 0; c < REMO_MAX_RHS; ++c) { out.iters[c] = 0; out.relres[c] = 0.0; }
+    double rz0g[REMO_MAX_RHS] = {0}, floor[REMO_MAX_RHS] = {0}, first[REMO_MAX_RHS], last[REMO_MAX_RHS];
+    HIP_TRY(hipMemsetAsync(buf.x, 0, sizeof(double) * nk, s));
+    int total = 0;
+    const int max_cycles = 40;
+    for (int cycle = 0; cycle < max_cycles; ++cycle) {
+        if (cycle == 0) {
+            launch_mixed_residual(nk, d_f, nullptr, mx.f32, s);
+        } else {
+            launch_spmm(A, k, (const double *)buf.x, buf.q, (double *)nullptr, (const double *)nullptr, buf.nb_spmv, s);
+            launch_mixed_residual(nk, d_f, buf.q, mx.f32, s);
+        }
+        const int budget = std::max(1, o.maxsteps - total);
+        ChunkResult in = run_pcg_t<float>(ctx, mx.A32, k, mx.f32, mx.b32, tol2_in, cycle ? floor : nullptr, budget, o.check_every,
+                                          o.time_kernels != 0, st, ev_used, first, last);
+        if (cycle == 0)
+            for (int c = 0; c < k; ++c) { rz0g[c] = first[c]; floor[c] = 0.25 * tol2 * rz0g[c]; }   // inner target: half the outer one in norm
+        out.finite = out.finite && in.finite;
+        if (!in.finite) break;
+        bool met = true;
+        for (int c = 0; c < k; ++c) {
+            out.relres[c] = rz0g[c] > 0.0 ? std::sqrt(first[c] / rz0g[c]) : 0.0;   // TRUE residual at the start of this cycle
+            if (first[c] > tol2 * rz0g[c]) met = false;
+        }
+        if (met) { out.converged = true; break; }   // nothing to add: every column was frozen at step 0
+        launch_mixed_accumulate(nk, buf.x, mx.b32.x, s);
+        total += in.steps;
+        for (int c = 0; c < k; ++c) out.iters[c] += in.iters[c];
+        if (st) st->refinement_cycles += 1;
+        if (total >= o.maxsteps) break;
+    }
+    out.steps = total;
+    HIP_TRY(hipStreamSynchronize(s));
+    return out;
 }
 
 }  // namespace
@@ -380,6 +453,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
+        if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
+            need += size_t(nnz_max) * 4 + size_t(ndof_max) * 4 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 4 * 4 * size_t(kmax) + (1 << 16);
         ctx->reserve(need);
 
         // ---- dof numbering + CSR pattern (device) ------------------------------------------
@@ -402,7 +477,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.dinv = d_dinv;
         buf.part_pq = ctx->take<double>(kMaxPartialBlocks * 8);
         buf.part_rz = ctx->take<double>(kMaxPartialBlocks * 8 * 2);
-        buf.rz0 = ctx->take<double>(40);
+        buf.rz0 = ctx->take<double>(kScalarSlots);
         const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
         buf.nv_coarse = two_level ? sy.nvfree : 0;
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : 6) : 0;
@@ -480,6 +555,27 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int lpr = choose_lanes_per_row(n, sy.nnz);
         buf.nb_spmv = spmv_grid(n, lpr);
         buf.nb_vec = vec_grid(n);
+        const bool mixed = (o.precision == 1);
+        MixedBuffers mx;
+        if (mixed) {   // fp32 images of the system for the inner solver
+            float *v32 = ctx->take<float>(size_t(sy.nnz));
+            float *dinv32 = ctx->take<float>(size_t(n));
+            launch_to_float(sy.nnz, d_val, v32, s);
+            launch_to_float(n, d_dinv, dinv32, s);
+            mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
+            mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
+            PcgBuffersT<float> &f = mx.b32;
+            f.x = ctx->take<float>(size_t(n) * kmax); f.r = ctx->take<float>(size_t(n) * kmax);
+            f.p = ctx->take<float>(size_t(n) * kmax + 4); f.q = ctx->take<float>(size_t(n) * kmax);
+            mx.f32 = ctx->take<float>(size_t(n) * kmax);
+            f.dinv = dinv32;
+            f.part_pq = buf.part_pq; f.part_rz = buf.part_rz; f.rz0 = buf.rz0;
+            f.nv_coarse = buf.nv_coarse; f.cheb_degree = buf.cheb_degree; f.cheb_lmax = buf.cheb_lmax; f.cheb_lmin = buf.cheb_lmin;
+            f.cz = ctx->take<float>(nc); f.cres = ctx->take<float>(nc);
+            f.cd[0] = ctx->take<float>(nc); f.cd[1] = ctx->take<float>(nc);
+            f.progress = buf.progress; f.progress_len = buf.progress_len;
+            f.nb_spmv = buf.nb_spmv; f.nb_vec = buf.nb_vec;
+        }
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
         size_t ev_used = 0;
@@ -494,7 +590,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
                 launch_build_rhs(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, sy.eldof, d_C, d_M, k,
                                  d_f, d_fint + q0, s);
             HIP_TRY(hipEventRecord(ctx->ev[5], s));
-            ChunkResult cr = run_pcg(ctx, b->A, k, d_f, buf, o, st, ev_used);
+            ChunkResult cr = mixed ? run_pcg_mixed(ctx, b->A, k, d_f, buf, mx, o, st, ev_used) : run_pcg(ctx, b->A, k, d_f, buf, o, st, ev_used);
             HIP_TRY(hipEventRecord(ctx->ev[6], s));
             if (nq > 0)
                 launch_eval(dim, sy.condense, nq, d_prhs + q0, d_pI + q0, d_found + q0, d_phi + size_t(q0) * N, sy.eldof, d_C, d_M, k, buf.x,
@@ -524,7 +620,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         (void)hipEventElapsedTime(&m, ctx->ev[1], ctx->ev[2]); st->ms_assemble = m;
         (void)hipEventElapsedTime(&m, ctx->ev[2], ctx->ev[3]); st->ms_eval = m + ms_eval;
         st->ms_solve = ms_solve;
-        st->spmv_bytes = 12.0 * double(sy.nnz) + 4.0 * double(n) + 16.0 * double(kmax) * double(n);
+        st->spmv_bytes = mixed ? 8.0 * double(sy.nnz) + 4.0 * double(n) + 8.0 * double(kmax) * double(n)   // fp32 values and vectors
+                               : 12.0 * double(sy.nnz) + 4.0 * double(n) + 16.0 * double(kmax) * double(n);
         if (o.time_kernels) {
             // what an event bracket measures beyond the enclosed kernel: an empty pair on the same stream
             float overhead = 1e30f;

@@ -25,8 +25,10 @@ class RemoError(RuntimeError):
 
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
-              time_kernels=False, coarse_degree=0, coarse_ratio=0) -> RemoOpts:
-    """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50)."""
+              time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0) -> RemoOpts:
+    """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
+    precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
+    (BASELINE config 5); inner_digits: decimal digits per inner solve (0 = library default 4)."""
     L = _lib.load()
     o = RemoOpts()
     L.remo_opts_default(C.byref(o))
@@ -40,6 +42,10 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     o.time_kernels = 1 if time_kernels else 0
     o.coarse_degree = int(coarse_degree)
     o.coarse_ratio = int(coarse_ratio)
+    if precision not in ("fp64", "mixed"):
+        raise ValueError("precision must be 'fp64' or 'mixed'")
+    o.precision = 1 if precision == "mixed" else 0
+    o.inner_digits = int(inner_digits)
     return o
 
 

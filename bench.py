@@ -177,7 +177,7 @@ def main():
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
     roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
                     traffic=pmc_traffic(f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
-                                        int(agg["n"]), int(agg["nnz"])),
+                                        int(agg["n"]), int(agg["nnz"])) if args.precision == "fp64" else None,
                     kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if args.precision == "fp64" else "fp32 values and vectors"), launches=int(agg["spmv_launches"]),
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,

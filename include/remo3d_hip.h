@@ -65,7 +65,8 @@ typedef struct {
     int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default 15) */
     int32_t precision;      /* 0 = fp64 throughout; 1 = mixed (BASELINE config 5): PCG in fp32 storage inside an fp64
                                residual-refinement loop, stopping test on the true fp64 residual           */
-    int32_t inner_digits;   /* mixed: decimal digits gained per inner solve before the residual is refreshed (0 => 4) */
+    int32_t inner_digits;   /* mixed: the fp32 residual is replaced by the true fp64 one every time <Cr,r> has gained this
+                               many decimal digits (0 => 3; capped at 5, what an fp32 recurrence can hold)   */
     int32_t reserved[1];
 } remo_opts_t;
 

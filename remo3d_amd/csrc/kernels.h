@@ -72,7 +72,10 @@ int cheb_grid(int64_t nv);
 // mixed precision: conversions around the fp32 inner solve
 void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s);
 void launch_mixed_residual(int64_t n, const double *f, const double *q /* may be null */, float *r32, hipStream_t s);
-void launch_mixed_accumulate(int64_t n, double *x, const float *e, hipStream_t s);
+void launch_mixed_accumulate(int64_t n, double *x, float *e, int zero_e, hipStream_t s);
+// one PCG step's update with residual replacement (x32 += alpha p; x64 += x32; r32 = f - A64 x64; C r)
+void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, int k, int step, double tol2, const PcgBuffersT<float> &b,
+                        const double *f64, double *x64, double *q64, hipStream_t s);
 
 // point location on the borehole axis + shape values; found[] must be pre-set to INT_MAX
 void launch_locate(int dim, int64_t nt, const double *coords, const int32_t *conn, int npts, const double *pz,

@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgsT<T> ch, co
 }
 
 template <class T, int K>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int nb_spmv, int nb_rz, ChebArgsT<T> ch,
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int x_only, int nb_spmv, int nb_rz, ChebArgsT<T> ch,
                                                     const double *__restrict__ part_pq, const double *__restrict__ part_rz_cur,
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const T *__restrict__ p,
@@ -672,6 +672,13 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
         for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (x_only) {   // residual replacement step (mixed precision): r and the <Cr,r> partials come from k_mixed_replace
+        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) x[i * K + c] += T(alpha[c]) * p[i * K + c];
+        }
+        return;
     }
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const T d = dinv[i];
@@ -913,8 +920,50 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<T> ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
+    launch_cheb(A, k, b, nxt, s);
+}
+
+// Residual replacement of the mixed mode, in place of launch_pcg_update at the chosen steps:
+//   x32 += alpha p;  x64 += x32, x32 = 0;  r32 = float(f - A64 x64);  C r;  <Cr,r> partials
+// The search direction and the scalars carry on, so the Krylov process is not restarted; what is
+// removed is the drift of the fp32 recurrence residual from the true one.
+template <int K>
+__global__ void __launch_bounds__(256) k_mixed_replace(int64_t n, int64_t nv, const double *__restrict__ f, const double *__restrict__ q64,
+                                                       float *__restrict__ r, const float *__restrict__ dinv, double *__restrict__ part_rz_next,
+                                                       const double *__restrict__ scal) {
+    __shared__ double smem[16 * K];
+    if (solve_done(scal)) return;
+    double acc[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) acc[c] = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        const float d = dinv[i];
+        const bool coarse = i < nv;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const float ri = float(f[i * K + c] - q64[i * K + c]);
+            r[i * K + c] = ri;
+            acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);
+        }
+    }
+    block_sum<K>(acc, smem);
+    if (threadIdx.x < K) part_rz_next[blockIdx.x * K + threadIdx.x] = acc[threadIdx.x];
+}
+
+void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, int k, int step, double tol2, const PcgBuffersT<float> &b,
+                        const double *f64, double *x64, double *q64, hipStream_t s) {
+    const int64_t n = A.n;
+    const int g = b.nb_vec;
+    double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
+    double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
+    const ChebArgsT<float> ch = cheb_args(b);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
+    launch_mixed_accumulate(n * k, x64, b.x, 1, s);
+    launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0));
     launch_cheb(A, k, b, nxt, s);
 }
 
@@ -952,9 +1001,12 @@ __global__ void __launch_bounds__(256) k_mixed_residual(int64_t n, const double 
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
         r32[i] = float(q ? f[i] - q[i] : f[i]);
 }
-// x += e
-__global__ void __launch_bounds__(256) k_mixed_accumulate(int64_t n, double *__restrict__ x, const float *__restrict__ e) {
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) x[i] += double(e[i]);
+// x += e (and e = 0 when the inner solve carries on)
+__global__ void __launch_bounds__(256) k_mixed_accumulate(int64_t n, double *__restrict__ x, float *__restrict__ e, int zero) {
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        x[i] += double(e[i]);
+        if (zero) e[i] = 0.f;
+    }
 }
 static int stream_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
@@ -967,8 +1019,8 @@ void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s) {
 void launch_mixed_residual(int64_t n, const double *f, const double *q, float *r32, hipStream_t s) {
     hipLaunchKernelGGL(k_mixed_residual, dim3(stream_grid(n)), dim3(256), 0, s, n, f, q, r32);
 }
-void launch_mixed_accumulate(int64_t n, double *x, const float *e, hipStream_t s) {
-    hipLaunchKernelGGL(k_mixed_accumulate, dim3(stream_grid(n)), dim3(256), 0, s, n, x, e);
+void launch_mixed_accumulate(int64_t n, double *x, float *e, int zero, hipStream_t s) {
+    hipLaunchKernelGGL(k_mixed_accumulate, dim3(stream_grid(n)), dim3(256), 0, s, n, x, e, zero);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -128,10 +128,22 @@ struct ChunkResult {
 // One PCG solve in storage type T.  tol2: relative target on <Cr,r> (w.r.t. this solve's own start);
 // floor: optional absolute per-column floor of <Cr,r> (mixed mode: the outer target).  rz_first /
 // rz_last return <Cr,r> at the start and at the end.
+// fp64 side of a mixed-precision inner solve: where the residual replacements read and write
+struct RefineHooks {
+    const CsrView *A64 = nullptr;
+    const double *f64 = nullptr;
+    double *x64 = nullptr, *q64 = nullptr;
+    double factor2 = 1e-6;   // replace once <Cr,r> of some column has dropped by this factor since the last replacement
+    int replacements = 0;
+};
+
 template <class T>
 ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, PcgBuffersT<T> &buf, double tol2, const double *floor,
-                      int maxit, int check, bool time_kernels, remo_stats_t *st, size_t &ev_used, double *rz_first, double *rz_last) {
+                      int maxit, int check, bool time_kernels, remo_stats_t *st, size_t &ev_used, double *rz_first, double *rz_last,
+                      RefineHooks *hooks = nullptr) {
     ChunkResult res;
+    bool replace_next = false, have_ref = false;
+    double rz_ref[REMO_MAX_RHS] = {0};
     hipStream_t s = ctx->stream;
     if (check <= 0) check = 10;
     for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
@@ -154,7 +166,16 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
         } else {
             launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
         }
-        launch_pcg_update(A, k, step, tol2, buf, s);
+        bool replaced = false;
+        if constexpr (std::is_same<T, float>::value) {
+            if (hooks && replace_next) {
+                launch_pcg_replace(A, *hooks->A64, k, step, tol2, buf, hooks->f64, hooks->x64, hooks->q64, s);
+                hooks->replacements += 1;
+                replace_next = false;
+                replaced = true;
+            }
+        }
+        if (!replaced) launch_pcg_update(A, k, step, tol2, buf, s);
         launch_pcg_direction(A, k, step, tol2, buf, s);
         ++step;
         if (*done_step >= 0) { done = true; break; }   // the device froze every column: the queued launches are no-ops
@@ -180,6 +201,20 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
                 const PcgProgress &pr = ctx->progress[target % (ctx->progress_len - 1)];
                 for (int c = 0; c < k; ++c)
                     if (!std::isfinite(pr.rz[c])) { res.finite = false; done = true; }
+                if (hooks) {   // schedule a residual replacement when the (lagged) history has dropped far enough
+                    if (!have_ref) {
+                        for (int c = 0; c < k; ++c) rz_ref[c] = pr.rz[c];
+                        have_ref = true;
+                    } else {
+                        bool hit = false;
+                        for (int c = 0; c < k; ++c)
+                            if (rz_ref[c] > 0.0 && pr.rz[c] > 0.0 && pr.rz[c] <= hooks->factor2 * rz_ref[c]) hit = true;
+                        if (hit) {
+                            replace_next = true;
+                            for (int c = 0; c < k; ++c) rz_ref[c] = pr.rz[c];
+                        }
+                    }
+                }
             }
         }
     }
@@ -219,12 +254,15 @@ ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, P
                              nullptr);
 }
 
-// Mixed precision (BASELINE config 5): the fp64 system A x = f is solved by iterative refinement
-// whose corrections come from PCG in fp32 storage (matrix values, vectors, preconditioner); scalars and
-// the stopping test stay fp64.  Cycle: r = f - A x in fp64 -> e = PCG32(A32, r) to `digits` decimal
-// digits or down to the outer target, whichever comes first -> x += e.  A solve ends with a cycle
-// whose START already meets the target, i.e. the criterion is checked on the TRUE fp64 residual,
-// not on a recurrence.  <Cr,r> of the refinement is measured with the fp32 preconditioner.
+// Mixed precision (BASELINE config 5): PCG runs in fp32 storage (matrix values, vectors,
+// preconditioner; scalars fp64) and its residual is refreshed from fp64 as it goes.  Every time <Cr,r>
+// of a column has dropped by `inner_digits` decimal digits, the step's update is replaced by
+//   x64 += x32, x32 = 0, r32 = float(f - A64 x64)            (launch_pcg_replace)
+// while the search direction and the scalars carry on (residual replacement: the Krylov process is NOT
+// restarted, which restart-style refinement pays for with 30-60 % more steps on these matrices).
+// When the recurrence says converged, an outer cycle re-measures the TRUE residual in fp64; the solve
+// ends with a cycle whose START already meets the target (normally the second one, at the cost of one
+// fp64 SpMM and one inner step).  <Cr,r> is measured with the fp32 preconditioner.
 struct MixedBuffers {
     CsrViewT<float> A32{};
     PcgBuffersT<float> b32{};
@@ -236,7 +274,7 @@ ChunkResult run_pcg_mixed(remo_ctx *ctx, const CsrView &A, int k, const double *
     hipStream_t s = ctx->stream;
     const int64_t nk = A.n * k;
     const double tol2 = o.rtol * o.rtol;
-    const int digits = o.inner_digits > 0 ? o.inner_digits : 4;
+    const int digits = o.inner_digits > 0 ? std::min(o.inner_digits, 5) : 3;   // fp32 recurrences do not hold more than ~5 digits
     const double tol2_in = std::pow(10.0, -2.0 * digits);
     ChunkResult out;
     out.converged = false;
@@ -253,10 +291,13 @@ ChunkResult run_pcg_mixed(remo_ctx *ctx, const CsrView &A, int k, const double *
             launch_mixed_residual(nk, d_f, buf.q, mx.f32, s);
         }
         const int budget = std::max(1, o.maxsteps - total);
-        ChunkResult in = run_pcg_t<float>(ctx, mx.A32, k, mx.f32, mx.b32, tol2_in, cycle ? floor : nullptr, budget, o.check_every,
-                                          o.time_kernels != 0, st, ev_used, first, last);
+        RefineHooks hooks;
+        hooks.A64 = &A; hooks.f64 = d_f; hooks.x64 = buf.x; hooks.q64 = buf.q; hooks.factor2 = tol2_in;
+        ChunkResult in = run_pcg_t<float>(ctx, mx.A32, k, mx.f32, mx.b32, 0.5 * tol2, cycle ? floor : nullptr, budget, o.check_every,
+                                          o.time_kernels != 0, st, ev_used, first, last, &hooks);
+        if (st) st->refinement_cycles += hooks.replacements;
         if (cycle == 0)
-            for (int c = 0; c < k; ++c) { rz0g[c] = first[c]; floor[c] = 0.25 * tol2 * rz0g[c]; }   // inner target: half the outer one in norm
+            for (int c = 0; c < k; ++c) { rz0g[c] = first[c]; floor[c] = 0.5 * tol2 * rz0g[c]; }   // inner target: 0.7 of the outer one in norm
         out.finite = out.finite && in.finite;
         if (!in.finite) break;
         bool met = true;
@@ -265,7 +306,7 @@ ChunkResult run_pcg_mixed(remo_ctx *ctx, const CsrView &A, int k, const double *
             if (first[c] > tol2 * rz0g[c]) met = false;
         }
         if (met) { out.converged = true; break; }   // nothing to add: every column was frozen at step 0
-        launch_mixed_accumulate(nk, buf.x, mx.b32.x, s);
+        launch_mixed_accumulate(nk, buf.x, mx.b32.x, 0, s);
         total += in.steps;
         for (int c = 0; c < k; ++c) out.iters[c] += in.iters[c];
         if (st) st->refinement_cycles += 1;

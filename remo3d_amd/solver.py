@@ -28,7 +28,7 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
               time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0) -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
     precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
-    (BASELINE config 5); inner_digits: decimal digits per inner solve (0 = library default 4)."""
+    (BASELINE config 5); inner_digits: decimal digits of <Cr,r> between two residual replacements (0 = library default 3)."""
     L = _lib.load()
     o = RemoOpts()
     L.remo_opts_default(C.byref(o))

@@ -188,7 +188,7 @@ def test_two_level_preconditioner_same_solution_fewer_steps(which, mesh2d, mesh3
 def test_mixed_precision_refines_to_the_fp64_answer(which, pre, mesh2d, mesh3d, gpu_ctx):
     """BASELINE config 5: PCG in fp32 storage inside an fp64 residual-refinement loop.  The stopping test
     is on the true fp64 residual, so the potentials agree with the oracle as the fp64 path does
-    (1e-8 at rtol 1e-12; fp32 alone would stall near 1e-6), in more than one refinement cycle."""
+    (1e-8 at rtol 1e-12; fp32 alone would stall near 1e-6), with several residual replacements."""
     from remo3d_amd import solver
     mesh = mesh2d if which == "2d" else mesh3d
     o, ref = _oracle_solve(mesh, SIGMA3, True)
@@ -201,7 +201,7 @@ def test_mixed_precision_refines_to_the_fp64_answer(which, pre, mesh2d, mesh3d, 
         assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
     # the reference's default tolerance, other digits per cycle
     outs64, _, rc64 = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-8))
-    for digits in (2, 6):
+    for digits in (2, 5):
         outs32, st32, rc32 = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL,
                                                  solver.make_opts(preconditioner=pre, rtol=1e-8, precision="mixed", inner_digits=digits))
         assert rc64 == 0 and rc32 == 0

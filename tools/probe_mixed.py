@@ -16,8 +16,8 @@ w = wl["work"][0]
 ctx = solver.Context(0)
 b = ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"])
 ref = None
-for label, kw in [("fp64", dict()), ("mixed d=3", dict(precision="mixed", inner_digits=3)), ("mixed d=4", dict(precision="mixed", inner_digits=4)),
-                  ("mixed d=5", dict(precision="mixed", inner_digits=5)), ("fp64", dict())]:
+for label, kw in [("fp64", dict()), ("mixed d=2", dict(precision="mixed", inner_digits=2)), ("mixed d=3", dict(precision="mixed", inner_digits=3)),
+                  ("mixed d=4", dict(precision="mixed", inner_digits=4)), ("mixed d=5", dict(precision="mixed", inner_digits=5)), ("fp64", dict())]:
     for rep in range(2):
         rc = b.run(solver.make_opts(rtol=1e-8, time_kernels=True, **kw))
     u = np.concatenate([np.atleast_1d(x) for x in b.fetch()])

@@ -307,6 +307,9 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
         proj = np.concatenate([proj, np.ones(n_iface, bool)])          # interface points are pinned like boundary points
         on_axis = np.concatenate([on_axis, ip[:, 0] == 0.0])
 
+    is_iface = np.zeros(len(pts), bool)
+    if n_iface:
+        is_iface[len(pts) - n_iface:] = True
     # jitter strictly interior, off-plane points to break lattice degeneracies (seeded)
     on_plane = np.zeros(len(pts), bool) if dim == 2 else (pts[:, 1] == 0.0)
     if dim == 2:
@@ -390,6 +393,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     order = order[used[order]]
     new_id = np.full(len(pts), -1, dtype=np.int64); new_id[order] = np.arange(order.size)
     pts = pts[order]; conn = new_id[conn]
+    node_h, node_iface = hs[order], is_iface[order]
 
     valence = np.bincount(conn.ravel(), minlength=len(pts)).max()
     if valence > 400:   # a vertex shared by hundreds of elements means the hull was broken
@@ -402,7 +406,7 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
     exact = (np.pi * R * R / 2) if dim == 2 else (2.0 / 3.0 * np.pi * R ** 3)
     meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z],
                 volume=float(vol.sum()), volume_exact=float(exact), min_quality=float(qual.min()),
-                max_valence=int(valence), n_interface_points=int(n_iface))
+                max_valence=int(valence), n_interface_points=int(n_iface), node_h=node_h, node_iface=node_iface)
     return Mesh(dim, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)),
                 np.ascontiguousarray(mat), np.ascontiguousarray(bf.astype(np.int32)),
                 np.ascontiguousarray(bdir.astype(np.uint8)), meta)
@@ -484,3 +488,207 @@ def layer_interfaces_2d(local_formation_geometry: np.ndarray, local_borehole_geo
         if z1 > z0:
             polys.append(np.array([[fz, z0], [fz, z1]]))
     return polys
+
+
+# ---------------------------------------------------------------------------------------------
+# interface-conforming 3D meshes of dipping models
+
+
+def _revolve_triangulation(p2: np.ndarray, tri: np.ndarray, m: int, kappa: float):
+    """Revolve a 2D (r, z) triangulation about the axis r = 0 over the half circle in m sectors.
+    Returns (points [N3, 3] as (x, y, z), tets [T3, 4], parent triangle of every tet, 3D node ids of
+    the 2D nodes on plane j as an [N2, m + 1] table).  Nodes on the axis are shared by all planes.
+    Prisms / pyramids are cut with the smallest-vertex-number rule (Dompierre et al. 1999), which makes
+    the diagonals of the quadrilateral faces agree between neighbours without any search."""
+    n2 = len(p2)
+    on_axis = p2[:, 0] == 0.0
+    ids = np.empty((n2, m + 1), dtype=np.int64)
+    n_ax = int(on_axis.sum())
+    ids[on_axis, :] = np.arange(n_ax)[:, None]
+    off = np.nonzero(~on_axis)[0]
+    ids[off, :] = n_ax + np.arange(off.size)[:, None] * (m + 1) + np.arange(m + 1)[None, :]
+    th = np.arange(m + 1) * (np.pi / m)
+    pts = np.empty((n_ax + off.size * (m + 1), 3))
+    pts[:n_ax] = np.stack([np.zeros(n_ax), np.zeros(n_ax), p2[on_axis, 1]], 1)
+    r = kappa * p2[off, 0]
+    c, sn = np.cos(th), np.sin(th)
+    sn[0] = 0.0; sn[-1] = 0.0; c[0] = 1.0; c[-1] = -1.0            # exact symmetry plane
+    pts[n_ax:] = np.stack([(r[:, None] * c[None, :]).ravel(), (r[:, None] * sn[None, :]).ravel(),
+                           np.repeat(p2[off, 1], m + 1)], 1)
+    tets, parent = [], []
+    nax = on_axis[tri].sum(1)
+    for j in range(m):
+        lo, hi = ids[:, j], ids[:, j + 1]
+        # --- no axis vertex: prism V1..V6 = a0 b0 c0 a1 b1 c1
+        t0 = np.nonzero(nax == 0)[0]
+        if t0.size:
+            T = tri[t0]
+            V = np.stack([lo[T[:, 0]], lo[T[:, 1]], lo[T[:, 2]], hi[T[:, 0]], hi[T[:, 1]], hi[T[:, 2]]], 1)
+            # rotate so that the smallest id sits at V1 (prism symmetries: cyclic shifts of (abc), swap of the two caps)
+            k = np.argmin(V, axis=1)
+            perms = np.array([[0, 1, 2, 3, 4, 5], [1, 2, 0, 4, 5, 3], [2, 0, 1, 5, 3, 4],
+                              [3, 5, 4, 0, 2, 1], [4, 3, 5, 1, 0, 2], [5, 4, 3, 2, 1, 0]])
+            V = np.take_along_axis(V, perms[k], axis=1)
+            first = np.minimum(V[:, 1], V[:, 5]) < np.minimum(V[:, 2], V[:, 4])
+            A = np.where(first[:, None, None],
+                         np.stack([V[:, [0, 1, 2, 5]], V[:, [0, 1, 5, 4]], V[:, [0, 4, 5, 3]]], 1),
+                         np.stack([V[:, [0, 1, 2, 4]], V[:, [0, 4, 2, 5]], V[:, [0, 4, 5, 3]]], 1))
+            tets.append(A.reshape(-1, 4)); parent.append(np.repeat(t0, 3))
+        # --- one axis vertex: pyramid apex a, base b0 c0 c1 b1
+        t1 = np.nonzero(nax == 1)[0]
+        if t1.size:
+            T = tri[t1]
+            sh = np.argmax(on_axis[T], axis=1)                        # rotate the axis vertex to the front
+            T = np.take_along_axis(T, (sh[:, None] + np.arange(3)[None, :]) % 3, axis=1)
+            ap, b0, c0, c1, b1 = lo[T[:, 0]], lo[T[:, 1]], lo[T[:, 2]], hi[T[:, 2]], hi[T[:, 1]]
+            base = np.stack([b0, c0, c1, b1], 1)
+            kmin = np.argmin(base, axis=1)
+            diag_b0c1 = (kmin == 0) | (kmin == 2)
+            A = np.where(diag_b0c1[:, None, None],
+                         np.stack([np.stack([ap, b0, c0, c1], 1), np.stack([ap, b0, c1, b1], 1)], 1),
+                         np.stack([np.stack([ap, b0, c0, b1], 1), np.stack([ap, c0, c1, b1], 1)], 1))
+            tets.append(A.reshape(-1, 4)); parent.append(np.repeat(t1, 2))
+        # --- two axis vertices: one tetrahedron
+        t2 = np.nonzero(nax == 2)[0]
+        if t2.size:
+            T = tri[t2]
+            sh = np.argmin(on_axis[T], axis=1)                        # the off-axis vertex to the front
+            T = np.take_along_axis(T, (sh[:, None] + np.arange(3)[None, :]) % 3, axis=1)
+            tets.append(np.stack([lo[T[:, 1]], lo[T[:, 2]], lo[T[:, 0]], hi[T[:, 0]]], 1)); parent.append(t2)
+    return pts, np.concatenate(tets), np.concatenate(parent), ids
+
+
+def make_mesh_3d_conforming(R: float, local_formation_geometry: np.ndarray, local_borehole_geometry: np.ndarray, dip_rad: float,
+                            sources_z: Sequence[float] = (0.0,), snap_z: Sequence[float] = (), scale: float = 1.0, seed: int = 0,
+                            layer_cap: Optional["LayerCap"] = None, sectors: int = 6, exact_radius: float = 0.5) -> Mesh:
+    """Half-ball tetrahedral mesh whose faces follow the material interfaces of a dipping model, the
+    geometry the reference builds with OpenCASCADE (gmsh_functions.py:543-628): borehole = body of
+    revolution of the wall polyline, layer boundaries = planes z + x tan(dip) = const through the
+    boundary depths on the axis, flushed zones = coaxial cylinders cut by those planes.
+
+    In the sheared coordinates (x, y, z' = z + x tan(dip)) all of that is axisymmetric: the planes are
+    horizontal and the vertical cylinders stay what they are.  So the interface-conforming 2D mesh of the
+    dip-0 model (make_mesh(2, ..., interfaces=...), the mesher validated against the reference's 2D
+    logs) is revolved about the axis in `sectors` sectors over the half space y >= 0 (the reference's
+    size field h ~ rho asks for about three elements around the half circle at every radius), every
+    tetrahedron inherits the material of its parent triangle, and the vertices are sheared back.
+    Conformity holds by construction and is affine invariant.
+
+    * circles become regular polygons whose circumradius is scaled so that the polygon AREA equals the
+      circle's: every volume of revolution (mud column, flushed zones) is preserved exactly;
+    * a caliper that varies with depth is revolved as it is seen on the axis' own z' (exact for a
+      cylindrical hole, first order in radius * tan(dip) otherwise);
+    * the sheared ball is inscribed in the physical sphere |x| = R and its outer part (beyond
+      `exact_radius` of the way to the boundary) is stretched radially onto the sphere, so the Dirichlet
+      boundary is the reference's; within that fraction the dipping geometry is exact.
+    """
+    a = float(np.tan(dip_rad))
+    fg = np.asarray(local_formation_geometry, dtype=np.float64)
+    bg = np.asarray(local_borehole_geometry, dtype=np.float64)
+    m = int(sectors)
+    kappa = float(np.sqrt(np.pi / (m * np.sin(np.pi / m))))      # equal-area regular 2m-gon
+    # shear S: (x, z') -> (x, z' - a x); its singular values bound the radius of the sheared ball
+    smax = float(np.sqrt(1.0 + 0.5 * a * a + a * np.sqrt(1.0 + 0.25 * a * a)))
+    Rs = R / (smax * kappa)                                       # inscribed: the stretch below only ever pushes outwards
+    polys = layer_interfaces_2d(fg, bg, Rs)
+    inside_src = [z for z in list(sources_z) + list(snap_z) if abs(z) < Rs]
+    fn2 = layered_material_fn(2, fg, bg)
+    m2 = make_mesh(2, Rs, sources_z=inside_src, scale=scale, seed=seed, interfaces=polys, layer_cap=layer_cap, material_fn=fn2,
+                   h_max=0.2 * R)
+    p2 = m2.coords.copy()
+    p2[np.abs(p2[:, 0]) < 1e-12 * R, 0] = 0.0
+    pts, conn, parent, ids = _revolve_triangulation(p2, m2.conn.astype(np.int64), m, kappa)
+    mat = m2.mat[parent]
+    # Dirichlet surface: revolved rim nodes of the 2D mesh
+    rim2 = np.zeros(len(p2), bool)
+    rim2[np.unique(m2.bconn[m2.bdirichlet == 1])] = True
+    on_rim = np.zeros(len(pts), bool)
+    on_rim[np.unique(ids[rim2])] = True
+    # back to physical coordinates, then the outer shell onto the sphere
+    pts[:, 2] -= a * pts[:, 0]
+    rho = np.sqrt((pts ** 2).sum(1))
+    # boundary radius B of the sheared (and polygonally revolved) ball in every node's direction: a rim node IS the
+    # boundary in its own direction; for inner nodes take it from the same 2D ray: p2 scaled to |p2| = Rs
+    n2 = len(p2)
+    s2 = np.hypot(p2[:, 0], p2[:, 1])
+    t2 = np.clip(s2 / Rs, 0.0, 1.0)                                # fraction of the way to the boundary (sheared space)
+    t3 = np.zeros(len(pts))
+    for j in range(m + 1):
+        t3[ids[:, j]] = t2
+    safe = t3 > 0
+    B = np.where(safe, rho / np.where(safe, t3, 1.0), R)          # affine map: radius scales linearly along a ray
+    t1 = float(exact_radius)
+    w = np.clip((t3 - t1) / (1.0 - t1), 0.0, 1.0)
+    w = w * w * (3.0 - 2.0 * w)                                    # smoothstep: 0 inside, 1 on the boundary
+    stretch = 1.0 + (R / B - 1.0) * w
+    pts *= stretch[:, None]
+    pts[on_rim] *= (R / np.sqrt((pts[on_rim] ** 2).sum(1)))[:, None]
+    Q = pts[conn]
+    e1 = Q[:, 1] - Q[:, 0]; e2 = Q[:, 2] - Q[:, 0]; e3 = Q[:, 3] - Q[:, 0]
+    vol = np.abs(np.einsum("ij,ij->i", e1, np.cross(e2, e3))) / 6.0
+    edges = np.stack([np.sqrt(((Q[:, i] - Q[:, j]) ** 2).sum(1)) for i in range(4) for j in range(i + 1, 4)], 1)
+    qual = vol / np.sqrt((edges ** 2).mean(1)) ** 3 * (6 * np.sqrt(2))
+    if not (vol > 1e-12 * edges.max(1) ** 3).all():
+        raise RuntimeError("revolved mesh has a degenerate element")
+    # locality: Morton order of the nodes
+    q = np.floor((pts - pts.min(0)) / (pts.max(0) - pts.min(0) + 1e-300) * 1023).astype(np.int64)
+    key = np.zeros(len(pts), dtype=np.int64)
+    for bit in range(10):
+        for k in range(3):
+            key |= ((q[:, k] >> bit) & 1) << (bit * 3 + k)
+    order = np.argsort(key, kind="stable")
+    new_id = np.empty(len(pts), dtype=np.int64); new_id[order] = np.arange(len(pts))
+    pts = pts[order]; conn = new_id[conn]; on_rim = on_rim[order]
+    bf = _boundary_facets(conn)
+    bdir = np.all(on_rim[bf], axis=1)
+    valence = int(np.bincount(conn.ravel(), minlength=len(pts)).max())
+    meta = dict(R=R, scale=scale, seed=seed, sources_z=[float(s) for s in sources_z], volume=float(vol.sum()),
+                volume_exact=float(2.0 / 3.0 * np.pi * R ** 3), min_quality=float(qual.min()), max_valence=valence,
+                n_interface_points=int(m2.meta["n_interface_points"]), dip_rad=float(dip_rad), sectors=m, kappa=kappa,
+                sheared_radius=Rs, exact_radius=float(t1 * Rs / smax), n_triangles_2d=int(m2.n_elems))
+    return Mesh(3, np.ascontiguousarray(pts), np.ascontiguousarray(conn.astype(np.int32)), np.ascontiguousarray(mat.astype(np.int32)),
+                np.ascontiguousarray(bf.astype(np.int32)), np.ascontiguousarray(bdir.astype(np.uint8)), meta)
+
+
+def interface_straddlers(mesh: Mesh, local_formation_geometry, local_borehole_geometry, dip_rad: float, tol: float = 1e-7):
+    """Number of elements whose vertices lie strictly on both sides of a material interface (layer
+    plane, flushed-zone cylinder or borehole wall), i.e. elements a conforming mesh must not have.
+    For revolved 3D meshes (meta has "sectors") circles are the equal-area polygons of the mesher, and only
+    the part of the mesh inside meta["exact_radius"] is looked at (beyond it the geometry is stretched)."""
+    fg = np.asarray(local_formation_geometry, dtype=np.float64)
+    bg = np.asarray(local_borehole_geometry, dtype=np.float64)
+    a = np.tan(dip_rad)
+    c = mesh.coords
+    R = mesh.meta.get("R", np.inf)
+    limit = 0.9 * R
+    if mesh.dim == 2:
+        rho, z, zl = np.abs(c[:, 0]), c[:, 1], c[:, 1]
+    else:
+        rho, z, zl = np.hypot(c[:, 0], c[:, 1]), c[:, 2], c[:, 2] + a * c[:, 0]
+        if "sectors" in mesh.meta:      # nominal radius of the polygonal "circle" through the node
+            m, kappa = mesh.meta["sectors"], mesh.meta["kappa"]
+            th = np.arctan2(c[:, 1], c[:, 0])
+            phi = np.mod(th, np.pi / m) - np.pi / (2 * m)
+            rho = rho * np.cos(phi) / (kappa * np.cos(np.pi / (2 * m)))
+            limit = 0.98 * mesh.meta["exact_radius"]
+    count = np.zeros(mesh.n_elems, bool)
+    conn = mesh.conn
+
+    def straddle(f):
+        fe = f[conn]
+        return (fe.min(1) < -tol) & (fe.max(1) > tol)
+
+    rbn = np.interp(zl if "sectors" in mesh.meta else z, bg[:, 0], bg[:, 1])
+    count |= straddle(rho - rbn)
+    outside_bh = (rho[conn] >= rbn[conn] - tol).all(1)
+    for i in range(fg.shape[0] - 1):
+        b = fg[i, 1]
+        if abs(b) < R:
+            count |= straddle(zl - b) & outside_bh
+    for i in range(fg.shape[0]):
+        fz = fg[i, 2]
+        if not np.isnan(fz):
+            inlayer = ((zl[conn] >= fg[i, 0] - tol) & (zl[conn] <= fg[i, 1] + tol)).all(1)
+            count |= straddle(rho - fz) & inlayer
+    far = (np.sqrt((c ** 2).sum(1))[conn] > limit).any(1)     # interfaces are not tracked onto the far boundary
+    return int((count & ~far).sum())

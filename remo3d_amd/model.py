@@ -27,10 +27,14 @@ from . import geometry, meshgen, tasks, tools as tools_mod
 CONVERSION = {"M": 1.0, "DM": 0.1, "CM": 0.01, "MM": 0.001, "IN": 0.0254, "FT": 0.3048}
 
 
-def default_mesh_provider(scale: float = 1.0, seed: int = 0) -> Callable:
-    """Batch mesh factory.  3D: seeded half-ball meshes cached on the electrode pattern (the point cloud
-    depends only on the current-electrode offsets of the batch; materials by element centroid).
-    2D: interface-conforming half-disc meshes built per batch."""
+def default_mesh_provider(scale: float = 1.0, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
+    """Batch mesh factory.  2D: interface-conforming half-disc meshes built per batch.
+    3D, mesh_3d = "conforming" (default): the 2D conforming mesh of the window revolved in the sheared
+    frame of the dipping layers (meshgen.make_mesh_3d_conforming: every interface of the reference's
+    OpenCASCADE geometry is a union of element faces); "lattice": seeded graded half-ball meshes cached on
+    the electrode pattern, materials by element centroid (the bench's synthetic meshes)."""
+    if mesh_3d not in ("conforming", "lattice"):
+        raise ValueError("mesh_3d must be 'conforming' or 'lattice'")
     cache: Dict[tuple, meshgen.Mesh] = {}
 
     def provider(dim, domain_radius, batch, local_formation_geometry, local_borehole_geometry, dip_rad):
@@ -50,6 +54,11 @@ def default_mesh_provider(scale: float = 1.0, seed: int = 0) -> Callable:
             cap = meshgen.LayerCap(np.concatenate([fg[:1, 0], fg[:, 1]]))     # thin beds bound the element size
             return meshgen.make_mesh(2, domain_radius, sources_z=inside, scale=scale, seed=seed, interfaces=polys, material_fn=fn,
                                      layer_cap=cap)
+        if mesh_3d == "conforming":
+            fg = np.asarray(local_formation_geometry, dtype=float)
+            cap = meshgen.LayerCap(np.concatenate([fg[:1, 0], fg[:, 1]]))
+            return meshgen.make_mesh_3d_conforming(domain_radius, local_formation_geometry, local_borehole_geometry, dip_rad,
+                                                   sources_z=list(cur), snap_z=list(pot), scale=scale, seed=seed, layer_cap=cap, sectors=sectors)
         key = (dim, float(domain_radius), tuple(np.round(cur, 4)), tuple(np.round(pot, 4)), float(scale), seed)
         base = cache.get(key)
         if base is None:

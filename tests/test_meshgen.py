@@ -88,3 +88,44 @@ def test_conforming_2d_mesh_keeps_interfaces_as_edges():
     c = X[m.conn].mean(1)
     assert np.array_equal(fn(c), m.mat)
     assert set(np.unique(m.mat)) == {0, 1, 2, 3, 4}
+
+
+@pytest.mark.parametrize("dip_deg", [0.0, 30.0])
+def test_conforming_3d_mesh_of_a_dipping_model(dip_deg):
+    """The revolved mesh keeps every interface of the reference's 3D geometry (gmsh_functions.py:543-628) as
+    element faces: (almost) no element has vertices on both sides of the borehole wall, a dipping layer
+    plane or a flushed-zone cylinder; volumes of revolution are exact; the Dirichlet surface is the sphere."""
+    R = 50.0
+    dip = np.deg2rad(dip_deg)
+    fg = np.array([[-80.0, -1.0, np.nan], [-1.0, 1.5, 0.5], [1.5, 80.0, np.nan]])
+    bh = np.array([[-80.0, 0.1], [80.0, 0.1]])
+    m = meshgen.make_mesh_3d_conforming(R, fg, bh, dip, sources_z=[0.0], snap_z=[0.4, 6.4], scale=1.5)
+    assert m.dim == 3 and m.conn.min() == 0 and m.conn.max() == m.n_nodes - 1
+    assert np.unique(m.conn).size == m.n_nodes                            # no unused nodes
+    Q = m.coords[m.conn]
+    vol = np.abs(np.einsum("ij,ij->i", Q[:, 1] - Q[:, 0], np.cross(Q[:, 2] - Q[:, 0], Q[:, 3] - Q[:, 0]))) / 6.0
+    assert vol.min() > 0 and m.meta["min_quality"] > 5e-3
+    assert meshgen.interface_straddlers(m, fg, bh, dip) <= 1e-3 * m.n_elems
+    # mud column (material 0) between the planes z' = -5 and z' = 5: half a cylinder of radius 0.1
+    c = Q.mean(1)
+    sel = (m.mat == 0) & (np.abs(c[:, 2] + np.tan(dip) * c[:, 0]) < 5.0)
+    assert abs(vol[sel].sum() - 0.5 * np.pi * 0.1 ** 2 * 10.0) < 0.01 * 0.5 * np.pi * 0.1 ** 2 * 10.0
+    # materials: 0 mud, 1 upper layer, 2 flushed zone, 3 undisturbed middle layer, 4 lower layer
+    assert set(np.unique(m.mat)) == {0, 1, 2, 3, 4}
+    fn = meshgen.layered_material_fn(3, fg, bh, dip)
+    inner = np.sqrt((c ** 2).sum(1)) < 0.9 * m.meta["exact_radius"]
+    off_wall = np.abs(np.hypot(c[:, 0], c[:, 1]) - 0.1) > 0.02           # the polygonal wall differs from the circle by design
+    off_fz = np.abs(np.hypot(c[:, 0], c[:, 1]) - 0.5) > 0.1
+    ok = inner & off_wall & off_fz
+    assert (fn(c[ok]) == m.mat[ok]).mean() > 0.999                        # parent-triangle materials = analytic classification
+    # boundary: Dirichlet facets lie on the sphere, the rest on the symmetry plane y = 0
+    rad = np.sqrt((m.coords ** 2).sum(1))
+    assert np.allclose(rad[m.bconn[m.bdirichlet == 1]], R, rtol=0, atol=1e-9)
+    assert np.allclose(m.coords[m.bconn[m.bdirichlet == 0]][:, :, 1], 0.0, atol=1e-12)
+    assert m.coords[:, 1].min() >= 0.0 and rad.max() <= R * (1 + 1e-12)
+    # electrodes are mesh vertices on the axis
+    for zs in (0.0, 0.4, 6.4):
+        assert np.min(np.abs(m.coords[:, 2] - zs) + np.hypot(m.coords[:, 0], m.coords[:, 1])) < 1e-12
+    # seeded: same arguments, same mesh
+    m_again = meshgen.make_mesh_3d_conforming(R, fg, bh, dip, sources_z=[0.0], snap_z=[0.4, 6.4], scale=1.5)
+    assert np.array_equal(m.conn, m_again.conn) and np.array_equal(m.coords, m_again.coords)

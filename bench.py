@@ -33,7 +33,7 @@ SIZES = {"S": 4.0, "M": 2.5, "L": 1.2, "XL": 0.7}   # multiplier on the referenc
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def build_workload(rank, world, depths_per_gpu, scale, dim=3):
+def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice"):
     from remo3d_amd import geometry, tasks, tools
     from remo3d_amd.model import Model, default_mesh_provider
     ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
@@ -45,7 +45,7 @@ def build_workload(rank, world, depths_per_gpu, scale, dim=3):
     sim, batches = tasks.build_batches(m.tools, m.sec, depths, 5)
     mud = np.interp(sim, m.borehole_model[:, 0], m.borehole_model[:, 2])
     bg = np.ascontiguousarray(m.borehole_model[:, :2])
-    provider = default_mesh_provider(scale=scale, seed=0)
+    provider = default_mesh_provider(scale=scale, seed=0, mesh_3d=mesh_3d)
     work = []
     t0 = time.time()
     for bi in range(rank, len(batches), world):
@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxsteps", type=int, default=1000)
+    ap.add_argument("--mesh", default="lattice", choices=["lattice", "conforming"],
+                    help="lattice = the seeded synthetic half-ball meshes of SURVEY 8d (headline workload); conforming = the interface-"
+                         "conforming revolved meshes Model uses by default for dipping models")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -119,7 +122,7 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
 
-    wl = build_workload(rank, world, args.depths, SIZES[args.size])
+    wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh)
     work = wl["work"]
     ctx = solver.Context(local)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
@@ -172,11 +175,14 @@ def main():
 
     n_points = len(wl["depths"]) * n_tools
     value = n_points * args.steps / dt
+    workload_name = f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}"
+    if args.mesh != "lattice":
+        workload_name += ", interface-conforming revolved meshes"
     if rank != 0:
         return
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
     roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
-                    traffic=pmc_traffic(f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
+                    traffic=pmc_traffic(workload_name,
                                         int(agg["n"]), int(agg["nnz"])) if args.precision == "fp64" else None,
                     kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if args.precision == "fp64" else "fp32 values and vectors"), launches=int(agg["spmv_launches"]),
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
@@ -186,7 +192,7 @@ def main():
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f64" if args.precision == "fp64" else "f32 PCG inside f64 residual refinement", data="synthetic",
-               config=dict(workload=f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}",
+               config=dict(workload=workload_name,
                            batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
                            mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
                            maxsteps=args.maxsteps, precision=args.precision, preconditioner="multigrid = Chebyshev(6) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),

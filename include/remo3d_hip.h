@@ -61,8 +61,8 @@ typedef struct {
     int32_t check_every;    /* host looks at the residual history every this many steps            */
     double rtol;            /* stop when sqrt(<Cr,r>) <= rtol * sqrt(<Cr0,r0>); NGSolve default 1e-8 */
     int32_t time_kernels;   /* 1 = bracket every SpMV launch with HIP events (bench roofline)      */
-    int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default 6) */
-    int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default 15) */
+    int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default: 6 in 3D, 8 in 2D) */
+    int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default: 60 in 3D, 120 in 2D) */
     int32_t precision;      /* 0 = fp64 throughout; 1 = mixed (BASELINE config 5): PCG in fp32 storage inside an fp64
                                residual-refinement loop, stopping test on the true fp64 residual           */
     int32_t inner_digits;   /* mixed: the fp32 residual is replaced by the true fp64 one every time <Cr,r> has gained this

@@ -332,8 +332,8 @@ void remo_opts_default(remo_opts_t *o) {
     o->check_every = 5;
     o->rtol = 1e-8;         // NGSolve CGSolver default precision
     o->time_kernels = 0;
-    o->coarse_degree = 6;
-    o->coarse_ratio = 15;
+    o->coarse_degree = 0;   // 0 = by dimension: Chebyshev(6) on [lmax/60, lmax] in 3D, Chebyshev(8) on [lmax/120, lmax] in 2D
+    o->coarse_ratio = 0;
 }
 
 remo_ctx_t *remo_ctx_create(int device_id) {
@@ -521,7 +521,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.rz0 = ctx->take<double>(kScalarSlots);
         const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
         buf.nv_coarse = two_level ? sy.nvfree : 0;
-        buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : 6) : 0;
+        buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : (dim == 3 ? 6 : 8)) : 0;   // measured: tools/scan_coarse.py
         buf.cheb_lmax = buf.cheb_lmin = 0.0;
         const size_t nc = size_t(buf.nv_coarse) * kmax + 2;
         buf.cz = ctx->take<double>(nc); buf.cres = ctx->take<double>(nc);
@@ -578,7 +578,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             std::memcpy(&lmax, &h_bound, sizeof lmax);
             if (!(lmax > 0.0) || !std::isfinite(lmax)) return fail(ctx, REMO_ERR_NUMERIC, "vertex block has no positive spectrum bound");
             buf.cheb_lmax = lmax;
-            buf.cheb_lmin = lmax / double(o.coarse_ratio > 0 ? o.coarse_ratio : 15);
+            buf.cheb_lmin = lmax / double(o.coarse_ratio > 0 ? o.coarse_ratio : (dim == 3 ? 60 : 120));
         }
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");

@@ -105,6 +105,9 @@ def main():
                          "conforming revolved meshes Model uses by default for dipping models")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
+                         "1 = the headline configuration (per-launch SpMM timing is only meaningful without overlap)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
     args = ap.parse_args()
@@ -127,15 +130,24 @@ def main():
     ctx = solver.Context(local)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                             time_kernels=not args.no_events, precision=args.precision)
-    resident = [ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for w in work]
+    ctxs = [ctx] + [solver.Context(local) for _ in range(max(1, args.streams) - 1)]
+    resident = [ctxs[i % len(ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
     n_tools = len(wl["names"])
+    pool = None
+    if len(ctxs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=len(ctxs))
 
     def one_step():
         slab = np.zeros((len(wl["depths"]), n_tools))
         agg = dict(spmv_ms=0.0, spmv_launches=0, spmv_bytes_total=0.0, pcg_steps=0, not_converged=0, ms_symbolic=0.0, ms_assemble=0.0,
                    ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0)
-        for w, b in zip(work, resident):
-            rc = b.run(opts, raise_on_error=False)
+        if pool is not None:   # one host thread per context, each walks its own batches in order (ctypes releases the GIL)
+            def drive(j):
+                return [(i, resident[i].run(opts, raise_on_error=False)) for i in range(j, len(resident), len(ctxs))]
+            rcs = dict(p for chunk in pool.map(drive, range(len(ctxs))) for p in chunk)
+        for i, (w, b) in enumerate(zip(work, resident)):
+            rc = rcs[i] if pool is not None else b.run(opts, raise_on_error=False)
             st = b.stats
             if rc < 0:
                 for rd in w["readers"]:
@@ -195,7 +207,7 @@ def main():
                config=dict(workload=workload_name,
                            batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
                            mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, preconditioner="multigrid = Chebyshev(6, interval lmax/60..lmax) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=len(ctxs), preconditioner="multigrid = Chebyshev(6, interval lmax/60..lmax) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
                            batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline,
                breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],

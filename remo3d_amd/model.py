@@ -73,6 +73,21 @@ def default_mesh_provider(scale: float = 1.0, seed: int = 0, mesh_3d: str = "con
     return provider
 
 
+# mesh generation ahead of the solver, in spawned processes (numpy / scipy only: they never touch the GPU)
+_WORKER_PROVIDER = None
+
+
+def _mesh_worker_init(provider_kwargs):
+    global _WORKER_PROVIDER
+    _WORKER_PROVIDER = default_mesh_provider(**provider_kwargs)
+
+
+def _mesh_worker_run(job):
+    import types
+    dim, domain_radius, electrodes, fg, bh, dip_rad = job
+    return _WORKER_PROVIDER(dim, domain_radius, types.SimpleNamespace(electrodes=electrodes), fg, bh, dip_rad)
+
+
 class Model:
     conversion_table = CONVERSION
 
@@ -135,11 +150,11 @@ class Model:
         return self.set_formation_parameters(data, units[:-2])
 
     def set_formation_parameters(self, formation_parameters, formation_units=["M", "M", "M"]):
-        fp = formation_parameters
+        fp = np.array(formation_parameters, dtype=float)   # a copy (the reference converts the caller's array in place, remo3d.py:427)
         for i, u in enumerate(formation_units):
             if u not in CONVERSION:
                 raise ValueError("{} unit in formation model file not recognized. Allowed units: M, DM, CM, MM, IN, FT".format(u))
-            fp[:, i] *= CONVERSION[u]   # in place, like the reference (remo3d.py:427)
+            fp[:, i] *= CONVERSION[u]
         if (np.diff(fp[:, :2], axis=0) <= 0.0).any() or (fp[1:, 0] != fp[:-1, 1]).any():
             raise ValueError("Uncorrect formation model geometry")
         if np.nanmin(fp[:, [3, 4]]) <= 0.0:
@@ -151,7 +166,7 @@ class Model:
         return self.set_borehole_parameters(data, borehole_geometry_type=borehole_geometry_type, borehole_units=units[:-1])
 
     def set_borehole_parameters(self, borehole_parameters, borehole_geometry_type="diameter", borehole_units=["M", "M"]):
-        bp = borehole_parameters
+        bp = np.array(borehole_parameters, dtype=float)   # a copy: the caller's array is not converted in place
         if np.shape(bp)[0] < 2:
             raise ValueError("Borehole paramaters have to be defined for at least two depths")
         for i, u in enumerate(borehole_units):
@@ -223,7 +238,7 @@ class Model:
     # -- the sweep (remo3d.py:723-884 + workers/worker.py:74-142) ----------------------------------
     def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
                       condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: float = 1.0, rtol: float = 1e-8,
-                      maxsteps: int = 1000, verbose: bool = True):
+                      maxsteps: int = 1000, verbose: bool = True, mesh_workers: int = 0, precision: str = "fp64"):
         from . import solver, sweep
         start = time.time()
         measurement_depths = np.asarray(measurement_depths, dtype=float)
@@ -256,24 +271,42 @@ class Model:
         mud = np.interp(simulation_depths, self.borehole_model[:, 0], self.borehole_model[:, 2])
         if verbose and sweep.rank() == 0:
             print("{} simulation tasks prepared".format(len(batches)))
-        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps)
+        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision)
 
         n_tools = len(self.tools)
         results = np.zeros((len(measurement_depths), n_tools))
         t_solve = t_mesh = 0.0
         n_points = 0
-        for bi in sweep.my_share(len(batches)):
+
+        def window(bi):
+            if netgen_path:   # the reference's default 2D windowing (remo3d.py:776-779, worker.py:94)
+                return geometry.select_netgen_data_range(borehole_geometry, self.formation_model, mud[bi], simulation_depths[bi], domain_radius)
+            # Gmsh-path windowing (worker.py:84), the only one for dipping models
+            return geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0, mud[bi],
+                                              simulation_depths[bi], domain_radius)
+
+        # mesh_workers > 0: the default mesher runs ahead of the solver in that many spawned processes (the
+        # reference meshes inside its MPI workers, i.e. in parallel too: worker.py:84-97)
+        mine = list(sweep.my_share(len(batches)))
+        pool, pending = None, {}
+        if mesh_workers > 0 and mesh_provider is None and len(mine) > 1:
+            import multiprocessing
+            from concurrent.futures import ProcessPoolExecutor
+            pool = ProcessPoolExecutor(max_workers=int(mesh_workers), mp_context=multiprocessing.get_context("spawn"),
+                                       initializer=_mesh_worker_init, initargs=(dict(scale=mesh_scale),))
+            for bi in mine:
+                try:
+                    fg, bh, _ = window(bi)
+                    pending[bi] = pool.submit(_mesh_worker_run, (dim, domain_radius, batches[bi].electrodes, fg, bh, self.dip_rad))
+                except Exception:
+                    pass      # reported when the batch's turn comes
+        for bi in mine:
             batch = batches[bi]
             rows = [(r.depth_index, r.tool_index) for s in batch.solves for r in s.records]
             try:
                 t0 = time.time()
-                if netgen_path:   # the reference's default 2D windowing (remo3d.py:776-779, worker.py:94)
-                    fg, bh, sigma = geometry.select_netgen_data_range(borehole_geometry, self.formation_model, mud[bi],
-                                                                      simulation_depths[bi], domain_radius)
-                else:             # Gmsh-path windowing (worker.py:84), the only one for dipping models
-                    fg, bh, sigma = geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0,
-                                                               mud[bi], simulation_depths[bi], domain_radius)
-                mesh = provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
+                fg, bh, sigma = window(bi)
+                mesh = pending.pop(bi).result() if bi in pending else provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
                 sources, evals, readers = tasks.batch_rhs(batch, self.tools)
                 t1 = time.time()
                 outs, st, rc = self.ctx.solve_batch(mesh, sigma, sources, evals, opts)
@@ -287,6 +320,8 @@ class Model:
             except Exception:
                 for di, ti in rows:      # any failure in a batch -> NaN for its records (worker.py:135-138)
                     results[di, ti] = np.nan
+        if pool is not None:
+            pool.shutdown(wait=False, cancel_futures=True)
         results = sweep.combine(results)
         self.logs = {name: np.vstack([measurement_depths, results[:, i]]).T for i, name in enumerate(self.tools.keys())}
         self.timing = dict(total_s=time.time() - start, mesh_s=t_mesh, solve_s=t_solve, points=n_points, batches=len(batches))

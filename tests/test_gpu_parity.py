@@ -73,13 +73,15 @@ def test_spmv_matches_oracle(which, k, mesh2d, mesh3d, gpu_ctx):
     b.close()
 
 
-def test_more_rhs_than_one_chunk(mesh2d, gpu_ctx):
-    """11 right-hand sides -> chunks of 8 + 3; every column must equal its single-RHS solve."""
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_more_rhs_than_one_chunk(precision, mesh2d, gpu_ctx):
+    """11 right-hand sides -> chunks of 8 + 3; every column must equal its single-RHS solve (in the mixed
+    mode too, where every chunk runs its own refinement cycles)."""
     from remo3d_amd import solver
     zs = np.linspace(-0.5, 0.5, 11)
     src = [([z], [1.0]) for z in zs]
     ev = [[z + 0.4, z + 6.4] for z in zs]
-    opts = solver.make_opts(preconditioner="local", rtol=1e-12, maxsteps=20000)
+    opts = solver.make_opts(preconditioner="local", rtol=1e-12, maxsteps=20000, precision=precision)
     outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, src, ev, opts)
     assert rc == 0
     for i in (0, 7, 8, 10):

@@ -140,3 +140,32 @@ def test_netgen_path_windowing_matches_reference(fixture, examples_dir):
         np.testing.assert_allclose(fg, np.array(case["formation_geometry"], dtype=float), rtol=1e-13, atol=1e-13, equal_nan=True)
         np.testing.assert_allclose(bh, np.array(case["borehole_geometry"]), rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(sigma, case["sigma"], rtol=1e-13)
+
+
+def test_mesh_workers_deliver_the_same_meshes_as_inline_generation():
+    """simulate_logs(mesh_workers=N): the default mesher runs ahead of the solver in spawned processes; every
+    batch must receive exactly the mesh the inline path builds (seeded mesher, same window)."""
+    from remo3d_amd.model import Model
+
+    class RecordingContext:
+        def __init__(self):
+            self.seen = []
+
+        def solve_batch(self, mesh, sigma, sources, evals, opts):
+            self.seen.append((mesh.dim, mesh.n_nodes, mesh.n_elems, float(mesh.coords.sum()), int(mesh.mat.sum()), len(sigma)))
+            return [np.ones(len(e)) for e in evals], {}, 0
+
+        def close(self):
+            pass
+
+    form = np.array([[0.0, 12.0, np.nan, np.nan, 7.0], [12.0, 13.5, 0.6, 2.0, 30.0], [13.5, 60.0, np.nan, np.nan, 4.0]])
+    bore = np.array([[0.0, 0.2, 0.5], [60.0, 0.2, 0.5]])
+    seen = {}
+    for workers in (0, 2):
+        m = Model(["A0.4M6.0N"])
+        m.set_model_parameters(form, bore)
+        m.ctx = RecordingContext()
+        m.simulate_logs(np.arange(10.0, 16.0, 0.5), domain_radius=50, batch_size=4, mesh_scale=3.0, verbose=False, mesh_workers=workers)
+        seen[workers] = m.ctx.seen
+        assert not np.isnan(m.logs["A0.4M6.0N"][:, 1]).any()
+    assert len(seen[0]) == 3 and seen[0] == seen[2]

@@ -21,7 +21,7 @@ n, nnz = b.stats["n_free"], b.stats["nnz"]
 x = np.random.default_rng(0).standard_normal((n, 5))
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 L.remo_debug_tune(0, variant)
-for grid in (1024, 1280, 1536):
+for grid in (1024, 768):
     L.remo_debug_tune(4, grid)
     for mode in (0, 1, 2, 3):
         L.remo_debug_tune(5, mode)

@@ -33,7 +33,7 @@ def tune(variant, lpr, threads, mapping, grid):
 
 configs = []
 for variant, lpr, threads, mapping, grid in [
-    (1, 16, 256, 0, 1024), (3, 16, 256, 0, 1024), (3, 16, 256, 1, 1024), (3, 16, 256, 2, 1024), (3, 16, 256, 1, 768), (3, 16, 256, 1, 1280), (3, 16, 256, 1, 1536), (3, 8, 256, 1, 1024),
+    (1, 16, 256, 0, 1024), (3, 16, 256, 0, 1024), (3, 16, 256, 1, 1024), (3, 16, 256, 1, 896), (3, 16, 256, 1, 768), (3, 16, 256, 1, 640), (3, 16, 256, 1, 512), (3, 16, 256, 1, 256),
 ]:
     configs.append(dict(variant=variant, lpr=lpr, threads=threads, mapping=mapping, grid=grid))
 

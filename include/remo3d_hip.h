@@ -169,7 +169,9 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
 /* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
  * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row mapping of
  * variant 1 (0 grid-stride, 1 XCD-aware ranges, 2 / 3 per-workgroup blocked ranges), 4 grid size;
- * value 0 (mapping: -1) restores the default.  Process-global. */
+ * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
+ * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
+ * paired kernel.  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -30,6 +30,11 @@ template <class T> struct PcgBuffersT {
     double cheb_lmax, cheb_lmin;
     T *cz, *cres;           // [nv_coarse*k]
     T *cd[2];               // [nv_coarse*k] ping-pong Chebyshev directions
+    // paired Chebyshev steps (launch_vblock_square): the vertex block A_vv and B = A_vv D^-1 A_vv on B's pattern;
+    // sq_rowptr = nullptr -> one launch per Chebyshev step on A_vv alone
+    const int32_t *sq_rowptr = nullptr, *sq_col = nullptr;
+    const T *sq_a = nullptr, *sq_b = nullptr;
+    int sq_lanes = 16;      // lanes per row of the paired kernel (8 / 16 / 32 by the average row length of B)
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
@@ -67,6 +72,12 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
 template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s);
 void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s);
+// B = A_vv D^-1 A_vv (and A_vv itself) on the pattern of B, rows sorted; cnt / rowptr [nv + 1], col / a / b [capacity];
+// *flag (device int, pre-zeroed) is raised when a row has more than kSquareSlots distinct columns or the capacity
+// is too small: the caller then keeps the one-step path
+constexpr int kSquareSlots = 512;
+void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int32_t *sq_rowptr, int32_t *sq_col, double *sq_a, double *sq_b,
+                          int64_t capacity, int32_t *flag, hipStream_t s);
 int cheb_grid(int64_t nv);
 
 // mixed precision: conversions around the fp32 inner solve

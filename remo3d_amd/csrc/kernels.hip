@@ -845,6 +845,218 @@ void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsig
     hipLaunchKernelGGL(k_vblock_bound, dim3(int(g)), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, dinv, out_bits);
 }
 
+// ------------------------------------------------------------------------------------------
+// Squared vertex block.  A Chebyshev step is a launch of ~5 us on a block of ~1e4 rows: pure launch latency, and
+// there are 6 (3D) / 8 (2D) of them per PCG step.  Two consecutive Richardson factors of the same polynomial,
+//   res'' = (I - b M)(I - a M) res = res - (a + b) M res + a b M^2 res,   M = A_vv D^-1,
+// need M^2, i.e. B = A_vv D^-1 A_vv, once per matrix (a 2-hop pattern, ~65 entries per row in 3D): then ONE launch
+// applies two factors, and the chain is half as long.  The polynomial is the same (product over the Chebyshev
+// roots instead of the three-term recurrence), so the PCG iteration is unchanged up to rounding.
+// One wave per row: distinct 2-hop columns through an LDS hash set, sorted (bitonic, so that the result does
+// not depend on the insertion order), values by sorted-row lookups in a fixed order: bit-reproducible.
+
+__device__ __forceinline__ int32_t lower_bound_col(const int32_t *__restrict__ col, int32_t lo, int32_t hi, int32_t key) {
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (col[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int PASS>   // 0: count the distinct columns of every row; 1: fill (row offsets known)
+__global__ void __launch_bounds__(256) k_vblock_square(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       const double *__restrict__ val, const double *__restrict__ dinv,
+                                                       int32_t *__restrict__ cnt, const int32_t *__restrict__ sq_rowptr,
+                                                       int32_t *__restrict__ sq_col, double *__restrict__ sq_a, double *__restrict__ sq_b,
+                                                       int64_t capacity, int32_t *flag) {
+    __shared__ int32_t keys[4][kSquareSlots];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    const bool active = row < nv;
+    int32_t *K = keys[wave];
+    for (int sl = lane; sl < kSquareSlots; sl += 64) K[sl] = INT_MAX;
+    __syncthreads();
+    int32_t rs = 0, re = 0;
+    bool overflow = false;
+    if (active) {
+        rs = rowptr[row]; re = rowptr[row + 1];
+        for (int32_t p = rs; p < re; ++p) {
+            const int32_t k = col[p];
+            if (k >= nv) break;                       // wave-uniform: the vertex block leads the row
+            const int32_t ke = rowptr[k + 1];
+            for (int32_t q = rowptr[k] + lane; q < ke; q += 64) {
+                const int32_t j = col[q];
+                if (j >= nv) break;
+                uint32_t h = (uint32_t(j) * 2654435761u) >> 23;
+                bool placed = false;
+                for (int probe = 0; probe < kSquareSlots; ++probe) {
+                    const int32_t old = atomicCAS(&K[h], INT_MAX, j);
+                    if (old == INT_MAX || old == j) { placed = true; break; }
+                    h = (h + 1) & (kSquareSlots - 1);
+                }
+                overflow |= !placed;
+            }
+        }
+    }
+    __syncthreads();
+    int c = 0;
+    for (int sl = lane; sl < kSquareSlots; sl += 64) c += K[sl] != INT_MAX;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (__builtin_amdgcn_ballot_w64(overflow) != 0 || c > kSquareSlots - 64) {   // keep the table sparse enough to probe quickly
+        if (lane == 0) atomicOr(flag, 1);
+        c = 0;
+    }
+    if (PASS == 0) {
+        if (active && lane == 0) cnt[row] = c;
+        return;
+    }
+    // bitonic sort of the table (empty slots = INT_MAX end up last); every wave sorts its own table, the
+    // barriers keep the four waves of the block in step
+    for (int size = 2; size <= kSquareSlots; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = lane; t < kSquareSlots / 2; t += 64) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int32_t a = K[lo], b = K[hi];
+                if ((a > b) == up) { K[lo] = b; K[hi] = a; }
+            }
+        }
+    __syncthreads();
+    if (!active || c == 0) return;
+    const int64_t off = sq_rowptr[row];
+    if (off + c > capacity) {
+        if (lane == 0) atomicOr(flag, 2);
+        return;
+    }
+    for (int t = lane; t < c; t += 64) {
+        const int32_t j = K[t];
+        double a = 0.0, b = 0.0;
+        for (int32_t p = rs; p < re; ++p) {           // fixed order over the row's vertex entries
+            const int32_t k = col[p];
+            if (k >= nv) break;
+            if (k == j) a = val[p];
+            const int32_t ks = rowptr[k], ke = rowptr[k + 1];
+            const int32_t q = lower_bound_col(col, ks, ke, j);
+            if (q < ke && col[q] == j) b += val[p] * dinv[k] * val[q];
+        }
+        sq_col[off + t] = j;
+        sq_a[off + t] = a;
+        sq_b[off + t] = b;
+    }
+}
+
+// exclusive scan of cnt[0 .. n) into out[0 .. n]; one workgroup (n is the vertex count)
+__global__ void __launch_bounds__(1024) k_scan_counts(int64_t n, const int32_t *__restrict__ cnt, int32_t *__restrict__ out) {
+    __shared__ int64_t part[1024];
+    const int64_t chunk = (n + 1023) / 1024;
+    const int64_t b = int64_t(threadIdx.x) * chunk, e = (b + chunk < n) ? b + chunk : n;
+    int64_t sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += cnt[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int t = 0; t < 1024; ++t) { const int64_t v = part[t]; part[t] = run; run += v; }
+        out[n] = int32_t(run < INT_MAX ? run : INT_MAX);
+    }
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int64_t i = b; i < e; ++i) { out[i] = int32_t(run < INT_MAX ? run : INT_MAX); run += cnt[i]; }
+}
+
+void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int32_t *sq_rowptr, int32_t *sq_col, double *sq_a, double *sq_b,
+                          int64_t capacity, int32_t *flag, hipStream_t s) {
+    if (nv <= 0) return;
+    const int g = int((nv + 3) / 4);
+    int32_t *cnt = sq_col;   // the counts live in the (not yet used) column array: capacity >= nv is required by the caller
+    hipLaunchKernelGGL((k_vblock_square<0>), dim3(g), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, dinv, cnt, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (double *)nullptr, (double *)nullptr, capacity, flag);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, nv, cnt, sq_rowptr);
+    hipLaunchKernelGGL((k_vblock_square<1>), dim3(g), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, dinv, (int32_t *)nullptr, sq_rowptr, sq_col, sq_a, sq_b,
+                       capacity, flag);
+}
+
+// Two Chebyshev (Richardson) factors per launch, 16 lanes per row of B's pattern.  State: z and w = D^-1 res.
+//   t1 = A w, t2 = B w;   z += (a + b) w - a b D^-1 t1;   w' = w - (a + b) D^-1 t1 + a b D^-1 t2
+// FIRST: z = 0, w = D^-1 r formed on the fly; LAST: z is stored divided by dinv (the direction kernel treats it like
+// r) and the <r, z> partial sums are left for the PCG scalars.
+template <class T, int K, int LPR, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const T *__restrict__ va, const T *__restrict__ vb, const T *__restrict__ dinv,
+                                                   const T *__restrict__ w_old, T *__restrict__ w_new, T *__restrict__ z, double ab_sum_, double ab_prod_,
+                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
+    constexpr int RPB = 256 / LPR, U = 2;
+    static_assert(K <= LPR, "one column per lane after the transposing reduction");
+    if (solve_done(scal)) return;
+    const T ab_sum = T(ab_sum_), ab_prod = T(ab_prod_);
+    const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    int idx[K], own[K];
+    towner_init<K, LPR>(idx, own, sub);
+    const int mycol = idx[0];
+    const bool mine = own[0] != 0;
+    double dot = 0.0;
+    for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
+        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        const int64_t at = row * K + mycol;
+        T di = T(0), wi = T(0), zi = T(0), rr = T(0);
+        if (mine) {
+            di = dinv[row];
+            if (FIRST || LAST) rr = r[at];
+            wi = FIRST ? di * rr : w_old[at];
+            if (!FIRST) zi = z[at];
+        }
+        T t1[K], t2[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) { t1[c] = T(0); t2[c] = T(0); }
+        for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {   // U passes of loads in flight, as in the SpMM
+            int32_t j[U];
+            T a[U], b[U], w[U][K];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t p = p0 + u * LPR;
+                j[u] = -1; a[u] = T(0); b[u] = T(0);
+                if (p < re) { j[u] = col[p]; a[u] = va[p]; b[u] = vb[p]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < K; ++c) w[u][c] = T(0);
+                if (j[u] >= 0) {
+                    const T *wj = (FIRST ? r : w_old) + int64_t(j[u]) * K;
+                    const T dj = FIRST ? dinv[j[u]] : T(1);
+#pragma unroll
+                    for (int c = 0; c < K; ++c) w[u][c] = FIRST ? dj * wj[c] : wj[c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < K; ++c) { t1[c] += a[u] * w[u][c]; t2[c] += b[u] * w[u][c]; }
+        }
+        TReduce<K, LPR>::run(t1, sub);
+        TReduce<K, LPR>::run(t2, sub);
+        if (mine) {
+            const T zn = zi + ab_sum * wi - ab_prod * di * t1[0];
+            z[at] = LAST ? zn / di : zn;
+            if (!LAST) w_new[at] = wi - ab_sum * di * t1[0] + ab_prod * di * t2[0];
+            if (LAST) dot += double(rr) * double(zn);
+        }
+    }
+    if (LAST) {
+        __shared__ double smem[16 * K];
+        double dcol[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dcol[c] = (mine && c == mycol) ? dot : 0.0;
+        block_sum<K>(dcol, smem);
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+            if (threadIdx.x == c) part[blockIdx.x * K + c] = dcol[c];
+    }
+}
+
 int vec_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
@@ -858,7 +1070,6 @@ int cheb_grid(int64_t nv) {
     if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
     return int(g);
 }
-
 #define REMO_K_SWITCH(k, CALL) \
     switch (k) {               \
         case 1: { constexpr int KK = 1; CALL; } break; \
@@ -883,6 +1094,38 @@ template <class T> static ChebArgsT<T> cheb_args(const PcgBuffersT<T> &b) {
 // behind the nb_vec partials of the high-order part (slot = even / odd step buffer)
 template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
+    if (b.sq_rowptr && (b.cheb_degree & 1) == 0) {   // two Richardson factors of the Chebyshev polynomial per launch
+        const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
+        const int m = b.cheb_degree, np = m / 2;
+        // 3D rows of B hold ~65 entries (32 lanes per row), 2D rows ~19 (8 lanes)
+        const int g_last = cheb_grid(b.nv_coarse);
+        double *part = part_slot + int64_t(b.nb_vec) * k;
+        for (int j = 0; j < np; ++j) {
+            // roots of the shifted Chebyshev polynomial, paired from the two ends of the interval inwards
+            const double r1 = theta - delta * cos(M_PI * (2.0 * (j + 1) - 1.0) / (2.0 * m));
+            const double r2 = theta - delta * cos(M_PI * (2.0 * (m - j) - 1.0) / (2.0 * m));
+            const double a = 1.0 / r1, bb = 1.0 / r2;
+            const T *wold = b.cd[j & 1];
+            T *wnew = b.cd[(j + 1) & 1];
+            const bool first = (j == 0), last = (j + 1 == np);
+            // only the LAST launch leaves partial sums, so only it is tied to the cheb_grid slots
+            auto grid_for = [&](int lpr) { int64_t gg = (b.nv_coarse + 256 / lpr - 1) / (256 / lpr); if (last && gg > g_last) gg = g_last; if (gg > 4096) gg = 4096; return int(gg); };
+#define REMO_CHEB2(LPRV, F, L)                                                                                                                        \
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_pair<T, KK, LPRV, F, L>), dim3(grid_for(LPRV)), dim3(256), 0, s, b.nv_coarse, b.sq_rowptr, b.sq_col, b.sq_a, \
+                                        b.sq_b, b.dinv, wold, wnew, b.cz, a + bb, a * bb, b.r, part, b.rz0))
+#define REMO_CHEB2_FL(LPRV)                                 \
+    if (first && last) { REMO_CHEB2(LPRV, true, true); }    \
+    else if (first) { REMO_CHEB2(LPRV, true, false); }      \
+    else if (last) { REMO_CHEB2(LPRV, false, true); }       \
+    else { REMO_CHEB2(LPRV, false, false); }
+            if (b.sq_lanes >= 32) { REMO_CHEB2_FL(32) }
+            else if (b.sq_lanes >= 16) { REMO_CHEB2_FL(16) }
+            else { REMO_CHEB2_FL(8) }
+#undef REMO_CHEB2_FL
+#undef REMO_CHEB2
+        }
+        return;
+    }
     const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
     const double sig = theta / delta, inv_theta = 1.0 / theta;
     double rho = 1.0 / sig;

@@ -128,6 +128,9 @@ struct ChunkResult {
 // One PCG solve in storage type T.  tol2: relative target on <Cr,r> (w.r.t. this solve's own start);
 // floor: optional absolute per-column floor of <Cr,r> (mixed mode: the outer target).  rz_first /
 // rz_last return <Cr,r> at the start and at the end.
+int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
+int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
+
 // fp64 side of a mixed-precision inner solve: where the residual replacements read and write
 struct RefineHooks {
     const CsrView *A64 = nullptr;
@@ -494,7 +497,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
+        need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
+            need += size_t(nv + 64) * 200 * 8;
+        if (o.precision == 1)
             need += size_t(nnz_max) * 4 + size_t(ndof_max) * 4 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 4 * 4 * size_t(kmax) + (1 << 16);
         ctx->reserve(need);
 
@@ -566,10 +572,27 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         int32_t h_err = 0;
         unsigned long long h_bound = 0;
+        int32_t h_sq[2] = {1, 0};   // flag, entries
+        int32_t *sq_rowptr = nullptr, *sq_col = nullptr;
+        double *sq_a = nullptr, *sq_b = nullptr;
+        // paired steps pay off where B stays small: 2D (~19 entries per row: 81 vs 93 us per PCG step); in 3D B has ~65
+        // entries per row and three launches on it cost more than six on A_vv (153 vs 149 us) - forced by tune value 2
+        const bool want_square = two_level && (buf.cheb_degree % 2 == 0) && ((g_square == 1 && dim == 2) || g_square == 2);
         if (two_level) {  // spectrum bound of the Jacobi-scaled vertex block for the Chebyshev interval
             HIP_TRY(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long), s));
             launch_vblock_bound(buf.nv_coarse, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, d_dinv, d_bound, s);
             HIP_TRY(hipMemcpyAsync(&h_bound, d_bound, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        }
+        if (want_square) {   // B = A_vv D^-1 A_vv for the paired Chebyshev steps (kernels.hip)
+            const int64_t nvc = buf.nv_coarse, cap = nvc * 200;
+            sq_rowptr = ctx->take<int32_t>(size_t(nvc) + 2);
+            sq_col = ctx->take<int32_t>(size_t(cap));
+            sq_a = ctx->take<double>(size_t(cap)); sq_b = ctx->take<double>(size_t(cap));
+            int32_t *d_sqflag = ctx->take<int32_t>(1);
+            HIP_TRY(hipMemsetAsync(d_sqflag, 0, sizeof(int32_t), s));
+            launch_vblock_square(nvc, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, d_dinv, sq_rowptr, sq_col, sq_a, sq_b, cap, d_sqflag, s);
+            HIP_TRY(hipMemcpyAsync(&h_sq[0], d_sqflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&h_sq[1], sq_rowptr + nvc, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -579,6 +602,11 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             if (!(lmax > 0.0) || !std::isfinite(lmax)) return fail(ctx, REMO_ERR_NUMERIC, "vertex block has no positive spectrum bound");
             buf.cheb_lmax = lmax;
             buf.cheb_lmin = lmax / double(o.coarse_ratio > 0 ? o.coarse_ratio : (dim == 3 ? 60 : 120));
+        }
+        if (want_square && h_sq[0] == 0) {   // otherwise (a vertex of very high valence) the one-step launches stay
+            buf.sq_rowptr = sq_rowptr; buf.sq_col = sq_col; buf.sq_a = sq_a; buf.sq_b = sq_b;
+            const double avg = double(h_sq[1]) / double(buf.nv_coarse > 0 ? buf.nv_coarse : 1);
+            buf.sq_lanes = g_sq_lanes ? g_sq_lanes : (avg > 40.0 ? 32 : (avg > 14.0 ? 16 : 8));
         }
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
@@ -616,6 +644,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             f.cd[0] = ctx->take<float>(nc); f.cd[1] = ctx->take<float>(nc);
             f.progress = buf.progress; f.progress_len = buf.progress_len;
             f.nb_spmv = buf.nb_spmv; f.nb_vec = buf.nb_vec;
+            if (buf.sq_rowptr) {
+                float *a32 = ctx->take<float>(size_t(h_sq[1]) + 1), *b32 = ctx->take<float>(size_t(h_sq[1]) + 1);
+                launch_to_float(h_sq[1], buf.sq_a, a32, s);
+                launch_to_float(h_sq[1], buf.sq_b, b32, s);
+                f.sq_rowptr = buf.sq_rowptr; f.sq_col = buf.sq_col; f.sq_a = a32; f.sq_b = b32; f.sq_lanes = buf.sq_lanes;
+            }
         }
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
@@ -807,7 +841,11 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     }
 }
 
-void remo_debug_tune(int32_t key, int32_t value) { set_spmm_tuning(key, value); }
+void remo_debug_tune(int32_t key, int32_t value) {
+    if (key == 6) g_square = value;
+    else if (key == 7) g_sq_lanes = value;
+    else set_spmm_tuning(key, value);
+}
 
 int remo_host_element_matrix(int32_t dim, const double *X, double sigma, double *K_out) {
     if ((dim != 2 && dim != 3) || !X || !K_out) return REMO_ERR_ARG;

@@ -244,3 +244,24 @@ def test_3d_path_reproduces_the_axisymmetric_solution(gpu_ctx):
     assert rc2 == 0 and rc3 == 0
     for a, b in zip(u2, u3):
         assert np.max(np.abs(0.5 * b - a) / np.abs(a)) < 1e-2, (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["2d", "3d"])
+def test_paired_chebyshev_steps_are_the_same_preconditioner(which, mesh2d, mesh3d, gpu_ctx):
+    """Two Richardson factors of the Chebyshev polynomial per launch on B = A_vv D^-1 A_vv (remo_debug_tune key 6) is
+    the same polynomial as one three-term-recurrence step per launch: same PCG step counts (+-1), same potentials."""
+    from remo3d_amd import _lib, solver
+    mesh = mesh2d if which == "2d" else mesh3d
+    L = _lib.load()
+    got = {}
+    try:
+        for mode in (0, 2):
+            L.remo_debug_tune(6, mode)
+            outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10))
+            assert rc == 0
+            got[mode] = (np.concatenate(outs), st["iterations"][:3])
+    finally:
+        L.remo_debug_tune(6, 1)
+    assert np.max(np.abs(got[0][0] - got[2][0]) / np.abs(got[0][0])) < 1e-7
+    assert max(abs(a - b) for a, b in zip(got[0][1], got[2][1])) <= 2

@@ -10,7 +10,7 @@
 //   faces : 64-bit keys (a,b,c packed, 3 x nbits)   sort + unique
 //   dofs  : flags of Dirichlet facets -> exclusive scan -> free numbering
 //   adj   : (row, element<<5|local) pairs, stable sort by row
-//   CSR   : (row << 32 | col) keys of every element, sort + unique -> col, rowptr by search
+//   CSR   : (row << cbits | col) keys of every element, sort + unique -> col, rowptr by search
 #include "symbolic_gpu.h"
 
 #include <cstring>
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) k_element_rows(int64_t nt, int64_t ndof, 
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256) k_coo_keys(int64_t nt, int nld, int64_t nfree, const int32_t *__restrict__ eldof,
+__global__ void __launch_bounds__(256) k_coo_keys(int64_t nt, int nld, int64_t nfree, int cbits, const int32_t *__restrict__ eldof,
                                                   uint64_t *__restrict__ keys) {
     constexpr int N = P3<DIM>::NLD;
     const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one thread per (element, local row)
@@ -219,11 +219,12 @@ __global__ void __launch_bounds__(256) k_coo_keys(int64_t nt, int nld, int64_t n
     const int64_t t = idx / nld;
     const int i = int(idx - t * nld);
     const int32_t r = eldof[t * N + i];
-    const uint64_t sentinel = uint64_t(nfree) << 32;
+    // key = row << cbits | col with cbits = bits of nfree: only 2 cbits key bits take part in the radix sort
+    const uint64_t sentinel = uint64_t(nfree) << cbits;
     uint64_t *out = keys + idx * nld;
     for (int j = 0; j < nld; ++j) {
         const int32_t c = eldof[t * N + j];
-        out[j] = (r >= 0 && c >= 0) ? ((uint64_t(uint32_t(r)) << 32) | uint32_t(c)) : sentinel;
+        out[j] = (r >= 0 && c >= 0) ? ((uint64_t(uint32_t(r)) << cbits) | uint32_t(c)) : sentinel;
     }
 }
 
@@ -238,10 +239,10 @@ __global__ void __launch_bounds__(256) k_row_starts_u32(int64_t n, const uint32_
     }
     ptr[r] = int32_t(lo);
 }
-__global__ void __launch_bounds__(256) k_row_starts_u64(int64_t n, const uint64_t *__restrict__ keys, int64_t nkeys, int32_t *__restrict__ ptr) {
+__global__ void __launch_bounds__(256) k_row_starts_u64(int64_t n, int cbits, const uint64_t *__restrict__ keys, int64_t nkeys, int32_t *__restrict__ ptr) {
     const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r > n) return;
-    const uint64_t k = uint64_t(r) << 32;
+    const uint64_t k = uint64_t(r) << cbits;
     int64_t lo = 0, hi = nkeys;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -249,9 +250,9 @@ __global__ void __launch_bounds__(256) k_row_starts_u64(int64_t n, const uint64_
     }
     ptr[r] = int32_t(lo);
 }
-__global__ void __launch_bounds__(256) k_low32(int64_t n, const uint64_t *__restrict__ keys, int32_t *__restrict__ col) {
+__global__ void __launch_bounds__(256) k_low32(int64_t n, int cbits, const uint64_t *__restrict__ keys, int32_t *__restrict__ col) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) col[i] = int32_t(uint32_t(keys[i]));
+    if (i < n) col[i] = int32_t(uint32_t(keys[i] & ((uint64_t(1) << cbits) - 1)));
 }
 
 inline int grid_for(int64_t n) { return int((n + 255) / 256); }
@@ -393,10 +394,11 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     // ---- CSR pattern: sort + unique of every element's (row, col) keys ---------------------------
     const int64_t ncoo = nt * int64_t(nld) * nld;
     uint64_t *ck_in = ar.hi<uint64_t>(ncoo), *ck_sorted = ar.hi<uint64_t>(ncoo), *ck_u = ar.hi<uint64_t>(ncoo);
-    if (dim == 2) hipLaunchKernelGGL(k_coo_keys<2>, dim3(grid_for(npairs)), dim3(256), 0, s, nt, nld, nfree, out.eldof, ck_in);
-    else hipLaunchKernelGGL(k_coo_keys<3>, dim3(grid_for(npairs)), dim3(256), 0, s, nt, nld, nfree, out.eldof, ck_in);
+    const int cbits = bits_for(uint64_t(nfree));
+    if (dim == 2) hipLaunchKernelGGL(k_coo_keys<2>, dim3(grid_for(npairs)), dim3(256), 0, s, nt, nld, nfree, cbits, out.eldof, ck_in);
+    else hipLaunchKernelGGL(k_coo_keys<3>, dim3(grid_for(npairs)), dim3(256), 0, s, nt, nld, nfree, cbits, out.eldof, ck_in);
     {
-        const unsigned end_bit = unsigned(32 + bits_for(uint64_t(nfree)));
+        const unsigned end_bit = unsigned(2 * cbits);
         size_t tb = 0;
         HIP_OK(rocprim::radix_sort_keys(nullptr, tb, ck_in, ck_sorted, size_t(ncoo), 0u, end_bit, s));
         void *tmp = ar.hi<char>(tb + 256);
@@ -412,12 +414,12 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     uint64_t h_last = 0;
     if (h_u > 0) HIP_OK(hipMemcpy(&h_last, ck_u + (h_u - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
     int64_t nnz = int64_t(h_u);
-    if (h_u > 0 && (h_last >> 32) == uint64_t(nfree)) nnz -= 1;  // the sentinel of constrained pairs
+    if (h_u > 0 && (h_last >> cbits) == uint64_t(nfree)) nnz -= 1;  // the sentinel of constrained pairs
     if (nnz <= 0 || nnz >= (int64_t(1) << 31)) { err = "nnz out of range for 32-bit row pointers"; return REMO_ERR_ARG; }
     out.nnz = nnz;
     out.col = ar.lo<int32_t>(nnz);
-    hipLaunchKernelGGL(k_low32, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, ck_u, out.col);
-    hipLaunchKernelGGL(k_row_starts_u64, dim3(grid_for(nfree + 1)), dim3(256), 0, s, nfree, ck_u, nnz, out.rowptr);
+    hipLaunchKernelGGL(k_low32, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, cbits, ck_u, out.col);
+    hipLaunchKernelGGL(k_row_starts_u64, dim3(grid_for(nfree + 1)), dim3(256), 0, s, nfree, cbits, ck_u, nnz, out.rowptr);
     HIP_OK(hipStreamSynchronize(s));  // scratch is released below
     ar.hi_release(hi_mark2);
     out.nadj = 0;  // adjptr[nfree] on the device holds it

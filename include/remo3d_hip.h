@@ -60,7 +60,7 @@ typedef struct {
     int32_t maxsteps;       /* CG step limit, reference 1000 (ngsolve_functions.py:50)             */
     int32_t check_every;    /* host looks at the residual history every this many steps            */
     double rtol;            /* stop when sqrt(<Cr,r>) <= rtol * sqrt(<Cr0,r0>); NGSolve default 1e-8 */
-    int32_t time_kernels;   /* 1 = bracket every SpMV launch with HIP events (bench roofline)      */
+    int32_t time_kernels;   /* k > 0: bracket every k-th SpMV launch of a solve with HIP events (bench roofline); 0 = off */
     int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default: 6 in 3D, 8 in 2D) */
     int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default: 60 in 3D, 120 in 2D) */
     int32_t precision;      /* 0 = fp64 throughout; 1 = mixed (BASELINE config 5): PCG in fp32 storage inside an fp64
@@ -85,7 +85,7 @@ typedef struct {
     double ms_solve;     /* PCG, all RHS (device, HIP events)                                      */
     double ms_eval;      /* point location + RHS build + evaluation                                */
     double ms_total;     /* wall clock of the call                                                 */
-    double spmv_ms;      /* sum of event-timed SpMV launches (time_kernels = 1), minus the bracket
+    double spmv_ms;      /* sum of the event-timed SpMV launches (time_kernels > 0), minus the bracket
                             overhead below per launch                                             */
     int64_t spmv_launches;
     double spmv_bytes;   /* algorithmic bytes of ONE SpMV launch: 12 nnz + 4 n + 16 k n            */

@@ -142,7 +142,7 @@ struct RefineHooks {
 
 template <class T>
 ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, PcgBuffersT<T> &buf, double tol2, const double *floor,
-                      int maxit, int check, bool time_kernels, remo_stats_t *st, size_t &ev_used, double *rz_first, double *rz_last,
+                      int maxit, int check, int time_kernels, remo_stats_t *st, size_t &ev_used, double *rz_first, double *rz_last,
                       RefineHooks *hooks = nullptr) {
     ChunkResult res;
     bool replace_next = false, have_ref = false;
@@ -161,7 +161,8 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
     int step = 0;
     bool done = false;
     for (; step < maxit && !done;) {
-        if (time_kernels && ev_used + 2 <= ctx->spmv_ev.size()) {
+        // time_kernels = k: every k-th SpMM launch is bracketed with events (a bracket costs the stream ~1.5 us)
+        if (time_kernels > 0 && (step % time_kernels) == (time_kernels / 2) && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
             launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
@@ -253,7 +254,7 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
 
 ChunkResult run_pcg(remo_ctx *ctx, const CsrView &A, int k, const double *d_f, PcgBuffers &buf, const remo_opts_t &o,
                     remo_stats_t *st, size_t &ev_used) {
-    return run_pcg_t<double>(ctx, A, k, d_f, buf, o.rtol * o.rtol, nullptr, o.maxsteps, o.check_every, o.time_kernels != 0, st, ev_used, nullptr,
+    return run_pcg_t<double>(ctx, A, k, d_f, buf, o.rtol * o.rtol, nullptr, o.maxsteps, o.check_every, o.time_kernels, st, ev_used, nullptr,
                              nullptr);
 }
 
@@ -297,7 +298,7 @@ ChunkResult run_pcg_mixed(remo_ctx *ctx, const CsrView &A, int k, const double *
         RefineHooks hooks;
         hooks.A64 = &A; hooks.f64 = d_f; hooks.x64 = buf.x; hooks.q64 = buf.q; hooks.factor2 = tol2_in;
         ChunkResult in = run_pcg_t<float>(ctx, mx.A32, k, mx.f32, mx.b32, 0.5 * tol2, cycle ? floor : nullptr, budget, o.check_every,
-                                          o.time_kernels != 0, st, ev_used, first, last, &hooks);
+                                          o.time_kernels, st, ev_used, first, last, &hooks);
         if (st) st->refinement_cycles += hooks.replacements;
         if (cycle == 0)
             for (int c = 0; c < k; ++c) { rz0g[c] = first[c]; floor[c] = 0.5 * tol2 * rz0g[c]; }   // inner target: 0.7 of the outer one in norm

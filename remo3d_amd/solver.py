@@ -39,7 +39,7 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     o.maxsteps = int(maxsteps)
     o.rtol = float(rtol)
     o.check_every = int(check_every)
-    o.time_kernels = 1 if time_kernels else 0
+    o.time_kernels = int(time_kernels)     # True / 1: every SpMV launch, k: every k-th
     o.coarse_degree = int(coarse_degree)
     o.coarse_ratio = int(coarse_ratio)
     if precision not in ("fp64", "mixed"):

@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
                          "1 = the headline configuration (per-launch SpMM timing is only meaningful without overlap)")
+    ap.add_argument("--overlap", default="prepare", choices=["prepare", "all"],
+                    help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
+                         "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--event-stride", type=int, default=8,
@@ -132,7 +135,8 @@ def main():
     work = wl["work"]
     ctx = solver.Context(local)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
-                            time_kernels=0 if args.no_events else max(1, args.event_stride), precision=args.precision)
+                            time_kernels=0 if args.no_events else max(1, args.event_stride), precision=args.precision,
+                            serialize_solves=(args.streams > 1 and args.overlap == "prepare"))
     ctxs = [ctx] + [solver.Context(local) for _ in range(max(1, args.streams) - 1)]
     resident = [ctxs[i % len(ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
     n_tools = len(wl["names"])

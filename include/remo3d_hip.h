@@ -67,7 +67,9 @@ typedef struct {
                                residual-refinement loop, stopping test on the true fp64 residual           */
     int32_t inner_digits;   /* mixed: the fp32 residual is replaced by the true fp64 one every time <Cr,r> has gained this
                                many decimal digits (0 => 3; capped at 5, what an fp32 recurrence can hold)   */
-    int32_t reserved[1];
+    int32_t serialize_solves; /* 1: the solve phase of remo_batch_run (PCG + evaluation) takes a process-wide lock, so that with
+                               several contexts driven by several host threads only ONE batch is in its PCG at any time while the
+                               others number / assemble theirs beside it (software pipelining across batches); 0: no lock      */
 } remo_opts_t;
 
 typedef struct {

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
+#include <mutex>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -128,6 +130,7 @@ struct ChunkResult {
 // One PCG solve in storage type T.  tol2: relative target on <Cr,r> (w.r.t. this solve's own start);
 // floor: optional absolute per-column floor of <Cr,r> (mixed mode: the outer target).  rz_first /
 // rz_last return <Cr,r> at the start and at the end.
+std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
 
@@ -622,6 +625,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->has_system = true;
 
         // ---- solve, chunk by chunk --------------------------------------------------------
+        // serialize_solves: batches of other contexts may number and assemble beside this PCG, but not run theirs
+        std::unique_lock<std::mutex> solve_turn(g_solve_mutex, std::defer_lock);
+        if (o.serialize_solves) solve_turn.lock();
         const int lpr = choose_lanes_per_row(n, sy.nnz);
         buf.nb_spmv = spmv_grid(n, lpr);
         buf.nb_vec = vec_grid(n);

@@ -265,3 +265,18 @@ def test_paired_chebyshev_steps_are_the_same_preconditioner(which, mesh2d, mesh3
         L.remo_debug_tune(6, 1)
     assert np.max(np.abs(got[0][0] - got[2][0]) / np.abs(got[0][0])) < 1e-7
     assert max(abs(a - b) for a, b in zip(got[0][1], got[2][1])) <= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_two_half_spaces_image_solution_on_the_gpu(precision, gpu_ctx):
+    """Heterogeneous analytic pin: point source next to a plane interface between two conductivities (image
+    solution), differences of axis potentials to 5e-3 (the grounded sphere at R = 50 m shifts them all alike)."""
+    from remo3d_amd import solver
+    from test_oracle import _two_half_spaces
+    mesh, sigma, zs, exact = _two_half_spaces(1.0)
+    outs, st, rc = gpu_ctx.solve_batch(mesh, sigma, [([0.0], [1.0])], [list(zs)], solver.make_opts(rtol=1e-10, precision=precision))
+    assert rc == 0
+    got = outs[0]
+    d_got, d_ex = got[:-1] - got[1:], exact[:-1] - exact[1:]
+    assert np.max(np.abs(d_got - d_ex) / np.abs(d_ex)) < 5e-3, (d_got, d_ex)

@@ -70,3 +70,32 @@ def test_solve_batch_wrapper_matches_object_api(mesh2d):
     o = Oracle(mesh2d, SIGMA3)
     f, se, sf = o.rhs([0.0], [1.0]); u, *_ = o.pcg(f, 1e-12)
     assert np.allclose(out[:2], o.eval(u, [0.4, 6.4], (se, sf)), rtol=1e-9)
+
+
+def _two_half_spaces(scale):
+    """Point source at the origin of medium 1 (z < h), plane interface z = h to medium 2: image solution
+    u1 = I/(4 pi s1) (1/|z| + k/|2h - z|), u2 = I/(2 pi (s1 + s2) |z|), k = (s1 - s2)/(s1 + s2)."""
+    from remo3d_amd.meshgen import make_mesh
+    R, h, s1, s2 = 50.0, 1.5, 0.2, 0.02
+    iface = [np.array([[0.0, h], [np.sqrt(R * R - h * h), h]])]
+    zs = np.array([0.4, 1.0, -0.7, -3.0, 2.0, 4.0, 6.4])
+    mesh = make_mesh(2, R, [0.0], scale=scale, snap_z=list(zs), interfaces=iface,
+                     material_fn=lambda c: (c[:, 1] > h).astype(np.int32))
+    k = (s1 - s2) / (s1 + s2)
+    exact = np.where(zs < h, (1.0 / np.abs(zs) + k / np.abs(2 * h - zs)) / (4 * np.pi * s1), 1.0 / (2 * np.pi * (s1 + s2) * np.abs(zs)))
+    return mesh, [s1, s2], zs, exact
+
+
+def test_two_half_spaces_image_solution():
+    """Heterogeneous analytic pin: the oracle reproduces the image solution of a point source next
+    to a plane interface.  Differences of potentials are compared: the grounded sphere at R = 50 m shifts all of
+    them by almost the same constant."""
+    from oracle.fem_oracle import Oracle
+    mesh, sigma, zs, exact = _two_half_spaces(2.0)
+    o = Oracle(mesh, sigma)
+    f, se, sf = o.rhs([0.0], [1.0])
+    u, it, rr, rc = o.pcg(f, 1e-11, 50000)
+    assert rc == 0
+    got = o.eval(u, zs, (se, sf))
+    d_got, d_ex = got[:-1] - got[1:], exact[:-1] - exact[1:]
+    assert np.max(np.abs(d_got - d_ex) / np.abs(d_ex)) < 5e-3, (d_got, d_ex)

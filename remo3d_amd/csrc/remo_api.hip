@@ -851,6 +851,7 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
 void remo_debug_tune(int32_t key, int32_t value) {
     if (key == 6) g_square = value;
     else if (key == 7) g_sq_lanes = value;
+    else if (key == 8) set_symbolic_tuning(value);
     else set_spmm_tuning(key, value);
 }
 

@@ -56,4 +56,7 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
                        const int32_t *d_bconn, const uint8_t *d_bdir, bool condense, int32_t *d_err, DeviceSymbolic &out,
                        std::string &err);
 
+// probe hook: 0 = build the CSR pattern by the global sort instead of row by row
+void set_symbolic_tuning(int row_pattern);
+
 }  // namespace remo

@@ -210,6 +210,75 @@ __global__ void __launch_bounds__(256) k_element_rows(int64_t nt, int64_t ndof, 
     }
 }
 
+// CSR pattern row by row (the default; the sort of all T x nld^2 element pairs below is the fallback): one wave per
+// row walks the row's incident elements (adjacency above), puts their free dofs into an LDS hash set, counts (PASS 0)
+// or compacts the set and writes it out in ascending order by rank counting (PASS 1).  The candidates are the
+// same T x nld^2 pairs, but they never leave the CU: ~0.3 ms against ~1.8 ms for 25 M sorted keys at 63 k tetrahedra.
+// A row with more than kRowSlots - 256 distinct columns raises err bit 32 and the caller sorts instead.
+constexpr int kRowSlots = 1024;
+template <int PASS>
+__global__ void __launch_bounds__(256) k_row_pattern(int64_t nfree, int nld, int N, const int32_t *__restrict__ adjptr,
+                                                     const uint32_t *__restrict__ adj, const int32_t *__restrict__ eldof,
+                                                     int32_t *__restrict__ cnt, const int32_t *__restrict__ rowptr,
+                                                     int32_t *__restrict__ col, int32_t *errflag) {
+    __shared__ int32_t tab[4][kRowSlots];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    const bool active = row < nfree;
+    int32_t *T = tab[wave];
+    for (int sl = lane; sl < kRowSlots; sl += 64) T[sl] = INT_MAX;
+    __syncthreads();
+    bool overflow = false;
+    if (active) {
+        const int32_t a0 = adjptr[row];
+        const int32_t total = (adjptr[row + 1] - a0) * nld;
+        for (int32_t item = lane; item < total; item += 64) {
+            const int32_t ai = item / nld, j = item - ai * nld;
+            const int32_t c = eldof[int64_t(adj[a0 + ai] >> 5) * N + j];
+            if (c < 0) continue;
+            uint32_t h = (uint32_t(c) * 2654435761u) >> 22;
+            bool placed = false;
+            for (int probe = 0; probe < kRowSlots; ++probe) {
+                const int32_t old = atomicCAS(&T[h], INT_MAX, c);
+                if (old == INT_MAX || old == c) { placed = true; break; }
+                h = (h + 1) & (kRowSlots - 1);
+            }
+            overflow |= !placed;
+        }
+    }
+    __syncthreads();
+    // compact the occupied slots to the front of a list (wave-wide prefix by ballot); the list reuses the table from the top
+    int c = 0;
+    int32_t mine[kRowSlots / 64];
+#pragma unroll
+    for (int b = 0; b < kRowSlots / 64; ++b) mine[b] = T[b * 64 + lane];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < kRowSlots / 64; ++b) {
+        const bool occ = mine[b] != INT_MAX;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
+        if (PASS == 1 && occ) T[c + __popcll(m & ((1ull << lane) - 1ull))] = mine[b];
+        c += __popcll(m);
+    }
+    if (__builtin_amdgcn_ballot_w64(overflow) != 0 || c > kRowSlots - 256) {
+        if (lane == 0) atomicOr(errflag, 32);
+        c = 0;
+    }
+    if (PASS == 0) {
+        if (active && lane == 0) cnt[row] = c;
+        return;
+    }
+    __syncthreads();
+    if (!active) return;
+    const int32_t off = rowptr[row];
+    for (int t = lane; t < c; t += 64) {      // ascending order by rank: the keys are distinct
+        const int32_t key = T[t];
+        int rank = 0;
+        for (int i = 0; i < c; ++i) rank += T[i] < key;   // LDS broadcast reads
+        col[off + rank] = key;
+    }
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(256) k_coo_keys(int64_t nt, int nld, int64_t nfree, int cbits, const int32_t *__restrict__ eldof,
                                                   uint64_t *__restrict__ keys) {
@@ -255,6 +324,7 @@ __global__ void __launch_bounds__(256) k_low32(int64_t n, int cbits, const uint6
     if (i < n) col[i] = int32_t(uint32_t(keys[i] & ((uint64_t(1) << cbits) - 1)));
 }
 
+int g_row_pattern = 1;   // 0: always build the pattern by sorting (A/B probe, set_symbolic_tuning)
 inline int grid_for(int64_t n) { return int((n + 255) / 256); }
 inline int bits_for(uint64_t v) {  // bits needed to represent values 0..v
     int b = 1;
@@ -391,7 +461,41 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     }
     hipLaunchKernelGGL(k_row_starts_u32, dim3(grid_for(nfree + 1)), dim3(256), 0, s, nfree, ak_out, npairs, out.adjptr);
 
-    // ---- CSR pattern: sort + unique of every element's (row, col) keys ---------------------------
+    // ---- CSR pattern, row by row through LDS ---------------------------------------------------------
+    if (g_row_pattern) {
+        int32_t *cnt = ar.hi<int32_t>(nfree + 1);
+        HIP_OK(hipMemsetAsync(cnt + nfree, 0, sizeof(int32_t), s));
+        const int gp = int((nfree + 3) / 4);
+        hipLaunchKernelGGL((k_row_pattern<0>), dim3(gp), dim3(256), 0, s, nfree, nld, N, out.adjptr, out.adj, out.eldof, cnt, (const int32_t *)nullptr,
+                           (int32_t *)nullptr, d_err);
+        {
+            size_t tb = 0;
+            HIP_OK(rocprim::exclusive_scan(nullptr, tb, cnt, out.rowptr, int32_t(0), size_t(nfree + 1), rocprim::plus<int32_t>(), s));
+            void *tmp = ar.hi<char>(tb + 256);
+            HIP_OK(rocprim::exclusive_scan(tmp, tb, cnt, out.rowptr, int32_t(0), size_t(nfree + 1), rocprim::plus<int32_t>(), s));
+        }
+        int32_t h_nnz = 0, h_err2 = 0;
+        HIP_OK(hipMemcpyAsync(&h_nnz, out.rowptr + nfree, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&h_err2, d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        if (!(h_err2 & 32)) {
+            if (h_nnz <= 0) { err = "empty matrix pattern"; return REMO_ERR_MESH; }
+            out.nnz = h_nnz;
+            out.col = ar.lo<int32_t>(h_nnz);
+            hipLaunchKernelGGL((k_row_pattern<1>), dim3(gp), dim3(256), 0, s, nfree, nld, N, out.adjptr, out.adj, out.eldof, (int32_t *)nullptr,
+                               (const int32_t *)out.rowptr, out.col, d_err);
+            HIP_OK(hipStreamSynchronize(s));  // scratch is released below
+            ar.hi_release(hi_mark2);
+            out.nadj = 0;
+            return REMO_OK;
+        }
+        // a row with more distinct columns than the LDS table holds: clear the bit and sort instead
+        int32_t cleared = h_err2 & ~32;
+        HIP_OK(hipMemcpyAsync(d_err, &cleared, sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+
+    // ---- CSR pattern (fallback): sort + unique of every element's (row, col) keys -----------------
     const int64_t ncoo = nt * int64_t(nld) * nld;
     uint64_t *ck_in = ar.hi<uint64_t>(ncoo), *ck_sorted = ar.hi<uint64_t>(ncoo), *ck_u = ar.hi<uint64_t>(ncoo);
     const int cbits = bits_for(uint64_t(nfree));
@@ -425,5 +529,7 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     out.nadj = 0;  // adjptr[nfree] on the device holds it
     return REMO_OK;
 }
+
+void set_symbolic_tuning(int row_pattern) { g_row_pattern = row_pattern; }
 
 }  // namespace remo

@@ -161,6 +161,16 @@ template <int K> __device__ __forceinline__ double pick(const double (&a)[K], in
     return r;
 }
 
+// Progress records live in mapped, coherent host memory: the stores bypass the caches (sc0 sc1).  A system-scope RELEASE
+// store would also write back the whole L2 of the XCD (buffer_wbl2) on every PCG step; the record only needs its data to
+// land before its step number, so the data stores are relaxed, the wave waits for their acknowledgement, then stores the
+// step number.
+__device__ __forceinline__ void publish_progress(PcgProgress *pr, const double *rz, int k, int step) {
+    for (int c = 0; c < k; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&pr->step, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // scal[kDoneSlot] (as int) is raised by the update launch once every column is frozen; the remaining
 // launches the host has already queued (it runs a few steps ahead of the device) then return at once.
 constexpr int kDoneSlot = 4 * 8;
@@ -661,10 +671,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         for (int c = 0; c < K; ++c) any_live |= (alpha[c] != 0.0);
         if (!any_live) {   // every column frozen: later launches of this solve are no-ops; tell the host where it ended
             reinterpret_cast<int *>(scal + kDoneSlot)[0] = 1;
-            PcgProgress *dn = progress + (progress_len - 1);
-#pragma unroll
-            for (int c = 0; c < K; ++c) __hip_atomic_store(&dn->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&dn->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            publish_progress(progress + (progress_len - 1), rz, K, step);
         }
 #pragma unroll
         for (int c = 0; c < K; ++c) scal[8 + c] = pq[c];
@@ -672,10 +679,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
             for (int c = 0; c < K; ++c) { rz0[c] = rz[c]; scal[16 + c] = rz[c]; }
         // progress record in mapped host memory: data first, then the step number (system scope)
-        PcgProgress *pr = progress + (step % (progress_len - 1));   // the last slot is the "done" record
-#pragma unroll
-        for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        publish_progress(progress + (step % (progress_len - 1)), rz, K, step);   // the last slot is the "done" record
     }
     if (x_only) {   // residual replacement step (mixed precision): r and the <Cr,r> partials come from k_mixed_replace
         for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
@@ -812,12 +816,7 @@ __global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_rz, const do
     if (solve_done(scal)) return;   // the "done" record already holds the final <Cr,r>
     double rz[K];
     reduce_partials<K>(part_rz, nb_rz, rz, smem);
-    if (threadIdx.x == 0) {
-        PcgProgress *pr = progress + (step % (progress_len - 1));
-#pragma unroll
-        for (int c = 0; c < K; ++c) __hip_atomic_store(&pr->rz[c], rz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&pr->step, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) publish_progress(progress + (step % (progress_len - 1)), rz, K, step);
 }
 
 // Gershgorin bound of the Jacobi-scaled vertex block: max_i dinv_i * sum_j |a_ij|, j < nv

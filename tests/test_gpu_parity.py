@@ -280,3 +280,26 @@ def test_two_half_spaces_image_solution_on_the_gpu(precision, gpu_ctx):
     got = outs[0]
     d_got, d_ex = got[:-1] - got[1:], exact[:-1] - exact[1:]
     assert np.max(np.abs(d_got - d_ex) / np.abs(d_ex)) < 5e-3, (d_got, d_ex)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_ragged_and_degenerate_right_hand_sides(precision, mesh2d, gpu_ctx):
+    """Edge cases of the batch entry (worker.py:104-131 never produces them, the ABI must still behave):
+    a zero-strength source is skipped (ngsolve_functions.py:43), a right-hand side without evaluation points,
+    one whose sources are all zero (u = 0, converged at once), an evaluation point on a source."""
+    from remo3d_amd import solver
+    opts = solver.make_opts(rtol=1e-10, precision=precision)
+    src = [([0.0, 0.1], [1.0, 0.0]),      # second electrode carries no current
+           ([0.1], [1.0]),                # no evaluation points at all
+           ([0.0], [0.0]),                # nothing injected
+           ([0.0], [1.0])]
+    ev = [[0.4, 6.4], [], [0.4, 6.4], [0.0, 0.4]]
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, src, ev, opts)
+    assert rc == 0, st
+    ref, _, rc1 = gpu_ctx.solve_batch(mesh2d, SIGMA3, [([0.0], [1.0])], [[0.4, 6.4, 0.0]], opts)
+    assert rc1 == 0
+    assert np.allclose(outs[0], ref[0][:2], rtol=1e-8, atol=0)
+    assert outs[1].size == 0
+    assert np.all(outs[2] == 0.0)
+    assert np.allclose(outs[3], [ref[0][2], ref[0][0]], rtol=1e-8, atol=0) and np.isfinite(outs[3][0]) and outs[3][0] > outs[3][1]

@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3
 
 
 def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice"):
-    from remo3d_amd import geometry, tasks, tools
+    from remo3d_amd import geometry, tasks
     from remo3d_amd.model import Model, default_mesh_provider
     ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
     names = ["A0.4M6.0N", "A2.0M0.5N"]

@@ -18,7 +18,7 @@ from __future__ import annotations
 import datetime
 import os
 import time
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Optional
 
 import numpy as np
 

@@ -6,8 +6,7 @@ the arrays that define a batch.  Everything numerical happens in libremo3d_hip.s
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 

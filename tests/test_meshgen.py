@@ -68,7 +68,7 @@ def test_conforming_2d_mesh_keeps_interfaces_as_edges():
         for a, b in ((0, 1), (0, 2), (1, 2)):
             edges.add((min(t[a], t[b]), max(t[a], t[b])))
     # points of the mesh that lie on each polyline, ordered along it, must be chained by edges
-    from scipy.spatial import cKDTree
+
     missing = total = 0
     for poly in polys:
         for a, b in zip(poly[:-1], poly[1:]):

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from remo3d_amd import geometry, meshgen, solver, tasks  # noqa: E402
+from remo3d_amd import geometry, solver, tasks  # noqa: E402
 from remo3d_amd.model import Model, default_mesh_provider  # noqa: E402
 
 ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 1")

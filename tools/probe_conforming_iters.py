@@ -7,7 +7,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
 from remo3d_amd import geometry, meshgen, solver, tasks  # noqa: E402
 from remo3d_amd.model import Model  # noqa: E402
 

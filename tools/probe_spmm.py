@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the SpMM variants on one assembled batch (one process, several rounds;
 cdna_hip_programming.md rule 24).  Usage on the GPU box:  python tools/probe_spmm.py [S|M] [k]"""
-import itertools
 import json
 import sys
 import os

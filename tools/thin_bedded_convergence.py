@@ -1,4 +1,4 @@
-import json, os, sys, time
+import os, sys
 import numpy as np
 ROOT='/root/repo'; sys.path.insert(0, ROOT)
 from remo3d_amd.model import Model

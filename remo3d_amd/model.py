@@ -246,7 +246,7 @@ class Model:
     # -- the sweep (remo3d.py:723-884 + workers/worker.py:74-142) ----------------------------------
     def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
                       condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: float = 1.0, rtol: float = 1e-8,
-                      maxsteps: int = 1000, verbose: bool = True, mesh_workers: int = 0, precision: str = "fp64"):
+                      maxsteps: int = 1000, verbose: bool = True, mesh_workers: Optional[int] = None, precision: str = "fp64"):
         from . import solver, sweep
         start = time.time()
         measurement_depths = np.asarray(measurement_depths, dtype=float)
@@ -297,17 +297,35 @@ class Model:
         # reference meshes inside its MPI workers, i.e. in parallel too: worker.py:84-97)
         mine = list(sweep.my_share(len(batches)))
         pool, pending = None, {}
+        if mesh_workers is None:    # default: the reference's cpu_workers mesh (and solve) in parallel; here they mesh, for sweeps long
+            mesh_workers = min(int(self.cpu_workers or 0), 8) if (mesh_provider is None and len(mine) >= 16) else 0   # enough to pay for the start-up
         if mesh_workers > 0 and mesh_provider is None and len(mine) > 1:
-            import multiprocessing
-            from concurrent.futures import ProcessPoolExecutor
-            pool = ProcessPoolExecutor(max_workers=int(mesh_workers), mp_context=multiprocessing.get_context("spawn"),
-                                       initializer=_mesh_worker_init, initargs=(dict(scale=mesh_scale),))
-            for bi in mine:
-                try:
-                    fg, bh, _ = window(bi)
-                    pending[bi] = pool.submit(_mesh_worker_run, (dim, domain_radius, batches[bi].electrodes, fg, bh, self.dip_rad))
-                except Exception:
-                    pass      # reported when the batch's turn comes
+            import sys
+            main_mod = sys.modules.get("__main__")
+            hidden = {}
+            try:
+                import multiprocessing
+                from concurrent.futures import ProcessPoolExecutor
+                # spawned children re-import the caller's __main__ (and would re-run a script without an
+                # `if __name__ == "__main__"` guard, GPU contexts and all): hide its path while the workers start -
+                # the worker functions live in this module, nothing of __main__ is needed over there
+                for attr in ("__file__", "__spec__"):
+                    if main_mod is not None and getattr(main_mod, attr, None) is not None:
+                        hidden[attr] = getattr(main_mod, attr)
+                        setattr(main_mod, attr, None)
+                pool = ProcessPoolExecutor(max_workers=int(mesh_workers), mp_context=multiprocessing.get_context("spawn"),
+                                           initializer=_mesh_worker_init, initargs=(dict(scale=mesh_scale),))
+                for bi in mine:      # worker processes are started by these submits
+                    try:
+                        fg, bh, _ = window(bi)
+                        pending[bi] = pool.submit(_mesh_worker_run, (dim, domain_radius, batches[bi].electrodes, fg, bh, self.dip_rad))
+                    except Exception:
+                        pass      # reported when the batch's turn comes
+            except Exception:     # no worker processes here: mesh inline
+                pool, pending = None, {}
+            finally:
+                for attr, v in hidden.items():
+                    setattr(main_mod, attr, v)
         import queue
         import threading
         ctxs = [self.ctx] + list(getattr(self, "extra_ctx", []))
@@ -323,7 +341,14 @@ class Model:
             try:
                 t0 = time.time()
                 fg, bh, sigma = window(bi)
-                mesh = pending.pop(bi).result() if bi in pending else provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
+                mesh = None
+                if bi in pending:
+                    try:
+                        mesh = pending.pop(bi).result()
+                    except Exception:     # a worker process died: mesh this batch here
+                        mesh = None
+                if mesh is None:
+                    mesh = provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
                 sources, evals, readers = tasks.batch_rhs(batch, self.tools)
                 t1 = time.time()
                 c = free_ctx.get()

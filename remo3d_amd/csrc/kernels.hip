@@ -1,9 +1,10 @@
 // kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the ReMo3D hot path:
-//   metric terms -> CSR value gather-assembly -> Jacobi-PCG (multi-RHS SpMM + fused vector
-//   kernels) -> axis point location / RHS build / evaluation.
-// All of it is HBM/L2-bound sparse fp64 work: no MFMA (a sparse row is not a dense contraction);
-// the levers are coalesced CSR streams, wave-shuffle reductions, LDS-staged reference tensors and
-// few launches per PCG step.  Reference lines each kernel replaces are cited at the kernel.
+//   metric terms -> CSR value gather-assembly -> multi-RHS PCG (edge-pair SpMM, fused vector kernels,
+//   two-level preconditioner: Chebyshev on the P1 vertex block + Jacobi; fp64 or fp32 storage with fp64
+//   residual replacement) -> axis point location / RHS build / evaluation.
+// All of it is HBM/L2-bound sparse work: no MFMA (a sparse row is not a dense contraction); the levers are
+// coalesced CSR streams, DPP (not LDS) cross-lane reductions, XCD-aware row placement, LDS-staged reference
+// tensors and few launches per PCG step.  Reference lines each kernel replaces are cited at the kernel.
 #include "kernels.h"
 
 #include <limits.h>

@@ -6,13 +6,12 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
-#include <mutex>
-
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>

@@ -49,14 +49,16 @@ template <class T> struct CsrViewT {
     const int32_t *col;
     const T *val;
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
-    // column patterns (0, 0 = unknown)
+    // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
 };
 using CsrView = CsrViewT<double>;
 
 void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,
                          const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s);
-void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowptr, const int32_t *col,
+// rows [pair_begin, pair_end) (the two dofs of every free edge) get their values interleaved: entry e of the first row
+// at rowptr[row] + 2e, of the second at rowptr[row] + 2e + 1 (CsrViewT below); all other rows plain CSR
+void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr, const int32_t *col,
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s);
 

@@ -172,6 +172,15 @@ __device__ __forceinline__ void publish_progress(PcgProgress *pr, const double *
     __hip_atomic_store(&pr->step, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Storage position of stored entry e of `row` (rows of an edge pair keep their values INTERLEAVED: the two rows have the
+// same column pattern and the SpMM reads both values of an entry with one 16-byte load; every other row is plain CSR).
+// rs = rowptr[row], len = row length.
+__device__ __forceinline__ int64_t value_pos(int64_t row, int32_t rs, int32_t len, int32_t e, int64_t pair_begin, int64_t pair_end) {
+    if (row < pair_begin || row >= pair_end) return int64_t(rs) + e;
+    const bool second = ((row - pair_begin) & 1) != 0;
+    return int64_t(second ? rs - len : rs) + 2 * int64_t(e) + (second ? 1 : 0);
+}
+
 // scal[kDoneSlot] (as int) is raised by the update launch once every column is frozen; the remaining
 // launches the host has already queued (it runs a few steps ahead of the device) then return at once.
 constexpr int kDoneSlot = 4 * 8;
@@ -226,7 +235,7 @@ void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_
 // Reference tensors are staged in LDS (19.2 KB in 3D, 7.2 KB in 2D).
 
 template <int DIM, bool CONDENSE>
-__global__ void __launch_bounds__(256) k_assemble(int64_t nfree, const int32_t *__restrict__ rowptr,
+__global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ adjptr,
                                                   const uint32_t *__restrict__ adj, const int32_t *__restrict__ eldof,
                                                   const double *__restrict__ C, const double *__restrict__ Mg,
@@ -265,22 +274,22 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, const int32_t *
             }
         }
         if (p < re) {
-            val[p] = acc;
+            val[value_pos(row, rs, re - rs, p - rs, pair_begin, pair_end)] = acc;
             if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
         }
     }
 }
 
-void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowptr, const int32_t *col,
+void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr, const int32_t *col,
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s) {
     const int grid = int((nfree + 3) / 4);
     if (dim == 3)
-        hipLaunchKernelGGL((k_assemble<3, false>), dim3(grid), dim3(256), 0, s, nfree, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
+        hipLaunchKernelGGL((k_assemble<3, false>), dim3(grid), dim3(256), 0, s, nfree, pair_begin, pair_end, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
     else if (condense)
-        hipLaunchKernelGGL((k_assemble<2, true>), dim3(grid), dim3(256), 0, s, nfree, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
+        hipLaunchKernelGGL((k_assemble<2, true>), dim3(grid), dim3(256), 0, s, nfree, pair_begin, pair_end, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
     else
-        hipLaunchKernelGGL((k_assemble<2, false>), dim3(grid), dim3(256), 0, s, nfree, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
+        hipLaunchKernelGGL((k_assemble<2, false>), dim3(grid), dim3(256), 0, s, nfree, pair_begin, pair_end, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,7 +305,7 @@ void launch_assemble(int dim, bool condense, int64_t nfree, const int32_t *rowpt
 // baseline of tools/probe_spmm.py.  T = double (the product path) or float (inner solver of the
 // mixed-precision mode); dot-product partials are always accumulated in double.
 template <class T, int K, int LPR, bool DOT>
-__global__ void __launch_bounds__(512) k_spmm(int64_t n, const int32_t *__restrict__ rowptr,
+__global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                               const int32_t *__restrict__ col, const T *__restrict__ val,
                                               const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
     if (scal && solve_done(scal)) return;
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, const int32_t *__restri
 #pragma unroll
         for (int c = 0; c < K; ++c) acc[c] = T(0);
         for (int32_t p = rs + sub; p < re; p += LPR) {
-            const T v = val[p];
+            const T v = val[value_pos(row, rs, re - rs, p - rs, pair_begin, pair_end)];
             const T *xr = x + int64_t(col[p]) * K;
 #pragma unroll
             for (int c = 0; c < K; ++c) acc[c] += v * xr[c];
@@ -397,7 +406,6 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
             rs_n = rowptr[row_n];
             re_n = rowptr[row_n + 1];
         }
-        const int32_t len = pair ? re - rs : 0;   // the second row's values sit `len` entries further
         T acc[2 * K];                             // [0, K): row, [K, 2K): row + 1
 #pragma unroll
         for (int c = 0; c < 2 * K; ++c) acc[c] = T(0);
@@ -410,8 +418,11 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
                 j[u] = -1; v0[u] = T(0); v1[u] = T(0);
                 if (p < re) {                        // lanes past the row end issue nothing (exec-masked loads)
                     j[u] = col[p];
-                    v0[u] = val[p];
-                    v1[u] = val[p + len];
+                    // one 16-byte (fp32: 8-byte) load either way: the interleaved values of the two rows of a pair, or a
+                    // single row's value plus its unused right neighbour (always inside the arena: other buffers follow val)
+                    typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+                    const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + (pair ? 2 * (p - rs) : (p - rs)));
+                    v0[u] = vv.x; v1[u] = vv.y;
                 }
             }
 #pragma unroll
@@ -518,9 +529,9 @@ int spmv_grid(int64_t n, int lpr) {
     const int64_t rpb = spmm_threads() / lpr;
     int64_t g = (n + rpb - 1) / rpb;
     g = (g + 7) / 8 * 8;  // whole residue classes mod 8 (one per XCD)
-    // whole multiples of the 256 CUs finish together; measured at k = 5 (329 k / 2.1 M rows): 1024 -> 59.7 / 518 us,
-    // 896 -> 65.9 / 569, 768 -> 59.3 / 493, 640 -> 71.3 / 562, 512 -> 73.4 / 566
-    constexpr int kSpmmBlocks = 768;
+    // whole multiples of the 256 CUs finish together; measured at k = 5, 329 k rows, interleaved pair values:
+    // 1024 -> 55.4 us, 896 -> 61.0, 768 -> 57.5, 640 -> 69.3 (before the interleaving 768 was ahead: 59.3 vs 59.7)
+    constexpr int kSpmmBlocks = 1024;
     static_assert(kSpmmBlocks <= kMaxPartialBlocks, "partials buffer");
     if (g > kSpmmBlocks) g = kSpmmBlocks;
     if (g < 8) g = 8;
@@ -536,9 +547,9 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 1;
 #define REMO_SPMM(L)                                                                                                        \
     if (part)                                                                                                               \
-        hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part, scal); \
+        hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \
     else                                                                                                                    \
-        hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.rowptr, A.col, A.val, x, y, part, scal)
+        hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
         hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \

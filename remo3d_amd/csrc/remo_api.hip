@@ -563,7 +563,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // ---- assembly ---------------------------------------------------------------------
         const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
         launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
-        launch_assemble(dim, sy.condense, n, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
+        int64_t pair_begin = 0, pair_end = 0;   // edge-dof rows: consecutive pairs with identical patterns, values interleaved
+        if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { pair_begin = sy.nvfree; pair_end = sy.nvefree; }
+        launch_assemble(dim, sy.condense, n, pair_begin, pair_end, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
 
         // ---- point location + shapes (all points at once) ---------------------------------
@@ -615,7 +617,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
-        if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { b->A.pair_begin = sy.nvfree; b->A.pair_end = sy.nvefree; }
+        b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;
@@ -809,7 +811,17 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int
         if (rowptr) HIP_TRY(hipMemcpy(rowptr, sy.rowptr, sizeof(int32_t) * (sy.nfree + 1), hipMemcpyDeviceToHost));
         if (col) HIP_TRY(hipMemcpy(col, sy.col, sizeof(int32_t) * sy.nnz, hipMemcpyDeviceToHost));
         if (freeid) HIP_TRY(hipMemcpy(freeid, sy.freeid, sizeof(int32_t) * sy.ndof, hipMemcpyDeviceToHost));
-        if (val) HIP_TRY(hipMemcpy(val, b->d_val, sizeof(double) * sy.nnz, hipMemcpyDeviceToHost));
+        if (val) {   // plain CSR order for the caller: undo the interleaving of the edge-pair rows
+            std::vector<double> raw(size_t(sy.nnz));
+            std::vector<int32_t> rp(size_t(sy.nfree) + 1);
+            HIP_TRY(hipMemcpy(raw.data(), b->d_val, sizeof(double) * sy.nnz, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rp.data(), sy.rowptr, sizeof(int32_t) * (sy.nfree + 1), hipMemcpyDeviceToHost));
+            std::memcpy(val, raw.data(), sizeof(double) * sy.nnz);
+            for (int64_t r = b->A.pair_begin; r + 1 < b->A.pair_end; r += 2) {
+                const int32_t rs = rp[r], len = rp[r + 1] - rp[r];
+                for (int32_t e = 0; e < len; ++e) { val[rs + e] = raw[rs + 2 * e]; val[rs + len + e] = raw[rs + 2 * e + 1]; }
+            }
+        }
         if (dinv) HIP_TRY(hipMemcpy(dinv, b->d_dinv, sizeof(double) * sy.nfree, hipMemcpyDeviceToHost));
         return REMO_OK;
     } catch (const std::exception &ex) {

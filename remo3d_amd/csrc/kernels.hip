@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         }
         return;
     }
+#pragma unroll 2
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const T d = dinv[i];
         const bool coarse = i < ch.nv;
@@ -810,6 +811,7 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
 #pragma unroll
             for (int c = 0; c < K; ++c) scal[16 + 8 * ((step + 1) & 1) + c] = rzn[c];   // read by the next update launch
     }
+#pragma unroll 2
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const T d = dinv[i];
         const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere

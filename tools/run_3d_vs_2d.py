@@ -19,7 +19,7 @@ from remo3d_amd.model import Model, default_mesh_provider  # noqa: E402
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 out = sys.argv[3] if len(sys.argv) > 3 else None
-sectors = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+sectors = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
 tools = ["A0.4M6.0N", "A2.0M0.5N"]
 depths = np.linspace(5.0, 20.0, nd, endpoint=False)

@@ -17,7 +17,8 @@
  * keeps a host pointer past return.  Return codes: 0 ok, >0 warning (REMO_NOT_CONVERGED — the
  * reference is silent about that, ngsolve_functions.py:50), <0 error (outputs NaN-filled, which
  * reproduces the reference's NaN-per-batch convention, worker.py:135-138).  No C++ exception
- * crosses the ABI.  One context per GPU, one calling thread per context.
+ * crosses the ABI.  One calling thread per context; contexts are independent (own stream and device arena),
+ * so one per GPU per process is the normal case and several may share a GPU (each with its own thread).
  */
 #ifndef REMO3D_HIP_H
 #define REMO3D_HIP_H

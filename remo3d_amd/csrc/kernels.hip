@@ -246,8 +246,8 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
     for (int i = threadIdx.x; i < NT * N * N; i += blockDim.x) M[i] = Mg[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t row = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= nfree) return;
+    // workgroups are persistent over rows: the reference tensors are staged in LDS once per workgroup, not once per 4 rows
+    for (int64_t row = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nfree; row += int64_t(gridDim.x) * (blockDim.x >> 6)) {
     const int32_t rs = rowptr[row], re = rowptr[row + 1];
     const int32_t as = adjptr[row], ae = adjptr[row + 1];
     for (int32_t base = rs; base < re; base += 64) {
@@ -278,12 +278,15 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
             if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
         }
     }
+    }
 }
 
 void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr, const int32_t *col,
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s) {
-    const int grid = int((nfree + 3) / 4);
+    int64_t g64 = (nfree + 3) / 4;
+    if (g64 > 4096) g64 = 4096;
+    const int grid = int(g64 < 1 ? 1 : g64);
     if (dim == 3)
         hipLaunchKernelGGL((k_assemble<3, false>), dim3(grid), dim3(256), 0, s, nfree, pair_begin, pair_end, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);
     else if (condense)

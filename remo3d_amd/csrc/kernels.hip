@@ -248,12 +248,16 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
     const int lane = threadIdx.x & 63;
     // workgroups are persistent over rows: the reference tensors are staged in LDS once per workgroup, not once per 4 rows
     for (int64_t row = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nfree; row += int64_t(gridDim.x) * (blockDim.x >> 6)) {
+    // the two dofs of an edge (rows r, r + 1 of the pair range) meet the same elements with local numbers li, li + 1 and
+    // have the same columns: the wave of the first row computes both (one column search), the wave of the second rests
+    const bool in_pairs = row >= pair_begin && row < pair_end;
+    if (in_pairs && ((row - pair_begin) & 1)) continue;
     const int32_t rs = rowptr[row], re = rowptr[row + 1];
     const int32_t as = adjptr[row], ae = adjptr[row + 1];
     for (int32_t base = rs; base < re; base += 64) {
         const int32_t p = base + lane;
         const int32_t j = (p < re) ? col[p] : -2;
-        double acc = 0.0;
+        double acc = 0.0, acc2 = 0.0;
         for (int32_t a = as; a < ae; ++a) {
             const uint32_t code = adj[a];  // wave-uniform
             const int64_t t = code >> 5;
@@ -266,16 +270,26 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
                 if (ed[q] == j) lj = q;
             if (lj >= 0) {
                 double k = kentry<DIM>(c, M, li, lj);
+                double k2 = in_pairs ? kentry<DIM>(c, M, li + 1, lj) : 0.0;
                 if (CONDENSE) {  // Schur complement of the cell bubble (condense=True, ngsolve_functions.py:31)
-                    const double kib = kentry<DIM>(c, M, li, 9), kbj = kentry<DIM>(c, M, 9, lj), kbb = kentry<DIM>(c, M, 9, 9);
-                    k -= kib * kbj / kbb;
+                    const double kbj = kentry<DIM>(c, M, 9, lj), kbb = kentry<DIM>(c, M, 9, 9);
+                    k -= kentry<DIM>(c, M, li, 9) * kbj / kbb;
+                    if (in_pairs) k2 -= kentry<DIM>(c, M, li + 1, 9) * kbj / kbb;
                 }
                 acc += k;
+                acc2 += k2;
             }
         }
         if (p < re) {
-            val[value_pos(row, rs, re - rs, p - rs, pair_begin, pair_end)] = acc;
-            if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
+            if (in_pairs) {   // interleaved values of the pair (value_pos): entry e of rows r, r + 1 at rs + 2e, rs + 2e + 1
+                val[int64_t(rs) + 2 * (p - rs)] = acc;
+                val[int64_t(rs) + 2 * (p - rs) + 1] = acc2;
+                if (j == row) dinv[row] = 1.0 / acc;
+                if (j == row + 1) dinv[row + 1] = 1.0 / acc2;
+            } else {
+                val[p] = acc;
+                if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
+            }
         }
     }
     }

@@ -62,8 +62,10 @@ typedef struct {
     int32_t check_every;    /* host looks at the residual history every this many steps            */
     double rtol;            /* stop when sqrt(<Cr,r>) <= rtol * sqrt(<Cr0,r0>); NGSolve default 1e-8 */
     int32_t time_kernels;   /* k > 0: bracket every k-th SpMV launch of a solve with HIP events (bench roofline); 0 = off */
-    int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default: 6 in 3D, 8 in 2D) */
-    int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default: 60 in 3D, 120 in 2D) */
+    int32_t coarse_degree;  /* "multigrid": Chebyshev degree on the vertex block (0 => default: 16 in 2D; in 3D 5 at 1e4 vertices,
+                               growing like sqrt(vertices) up to 16) */
+    int32_t coarse_ratio;   /* "multigrid": lmax / lmin of the Chebyshev interval (0 => default: 600 in 2D; in 3D 90 at 1e4 vertices, growing like
+                               vertices^(2/3)) */
     int32_t precision;      /* 0 = fp64 throughout; 1 = mixed (BASELINE config 5): PCG in fp32 storage inside an fp64
                                residual-refinement loop, stopping test on the true fp64 residual           */
     int32_t inner_digits;   /* mixed: the fp32 residual is replaced by the true fp64 one every time <Cr,r> has gained this

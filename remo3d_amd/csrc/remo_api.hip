@@ -338,7 +338,7 @@ void remo_opts_default(remo_opts_t *o) {
     o->check_every = 5;
     o->rtol = 1e-8;         // NGSolve CGSolver default precision
     o->time_kernels = 0;
-    o->coarse_degree = 0;   // 0 = by dimension: Chebyshev(6) on [lmax/60, lmax] in 3D, Chebyshev(8) on [lmax/120, lmax] in 2D
+    o->coarse_degree = 0;   // 0 = by dimension and size (remo_batch_run): e.g. Chebyshev(5) on [lmax/90, lmax] at 1e4 vertices in 3D
     o->coarse_ratio = 0;
 }
 
@@ -530,7 +530,13 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.rz0 = ctx->take<double>(kScalarSlots);
         const bool two_level = (o.preconditioner != 0) && sy.nvfree > 0;
         buf.nv_coarse = two_level ? sy.nvfree : 0;
-        buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : (dim == 3 ? 6 : 8)) : 0;   // measured: tools/scan_coarse.py
+        // Defaults from GPU scans (tools/scan_coarse2d.py, scan_coarse3d.py).  3D: the best degree / interval grow with the
+        // vertex count (kappa of the P1 block ~ nv^(2/3), degree ~ sqrt(kappa)): (5, 90) at 12.6 k vertices, (8-10, 150-200) at
+        // 24 k, (12-16, 300-600) at 80 k.  2D (launch-bound steps, paired Chebyshev launches): (16, 600).
+        const double nv_rel = double(sy.nvfree > 0 ? sy.nvfree : 1) / 12600.0;
+        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.5)))) : 16;
+        const double ratio_default = (dim == 3) ? std::min(1200.0, std::max(60.0, 90.0 * std::pow(nv_rel, 2.0 / 3.0))) : 600.0;
+        buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : deg_default) : 0;
         buf.cheb_lmax = buf.cheb_lmin = 0.0;
         const size_t nc = size_t(buf.nv_coarse) * kmax + 2;
         buf.cz = ctx->take<double>(nc); buf.cres = ctx->take<double>(nc);
@@ -606,7 +612,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             std::memcpy(&lmax, &h_bound, sizeof lmax);
             if (!(lmax > 0.0) || !std::isfinite(lmax)) return fail(ctx, REMO_ERR_NUMERIC, "vertex block has no positive spectrum bound");
             buf.cheb_lmax = lmax;
-            buf.cheb_lmin = lmax / double(o.coarse_ratio > 0 ? o.coarse_ratio : (dim == 3 ? 60 : 120));
+            buf.cheb_lmin = lmax / (o.coarse_ratio > 0 ? double(o.coarse_ratio) : ratio_default);
         }
         if (want_square && h_sq[0] == 0) {   // otherwise (a vertex of very high valence) the one-step launches stay
             buf.sq_rowptr = sq_rowptr; buf.sq_col = sq_col; buf.sq_a = sq_a; buf.sq_b = sq_b;

@@ -280,6 +280,7 @@ class Model:
         if verbose and sweep.rank() == 0:
             print("{} simulation tasks prepared".format(len(batches)))
         opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision)
+        tuned_coarse = mesh_provider is None and preconditioner == "multigrid"     # the default 3D provider = conforming revolved meshes
 
         n_tools = len(self.tools)
         results = np.zeros((len(measurement_depths), n_tools))
@@ -351,9 +352,18 @@ class Model:
                     mesh = provider(dim, domain_radius, batch, fg, bh, self.dip_rad)
                 sources, evals, readers = tasks.batch_rhs(batch, self.tools)
                 t1 = time.time()
+                bopts = opts
+                if tuned_coarse and mesh.dim == 3:
+                    # the revolved conforming meshes are graded and sheared: their P1 block wants a higher Chebyshev degree
+                    # and a wider interval than the library's default for isotropic meshes of the same vertex count
+                    # (GPU scan, tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)
+                    rel = max(mesh.n_nodes, 1) / 12600.0
+                    bopts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision,
+                                             coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))),
+                                             coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
                 c = free_ctx.get()
                 try:
-                    outs, st, rc = c.solve_batch(mesh, sigma, sources, evals, opts)
+                    outs, st, rc = c.solve_batch(mesh, sigma, sources, evals, bopts)
                 finally:
                     free_ctx.put(c)
                 t2 = time.time()

@@ -129,3 +129,27 @@ def test_conforming_3d_mesh_of_a_dipping_model(dip_deg):
     # seeded: same arguments, same mesh
     m_again = meshgen.make_mesh_3d_conforming(R, fg, bh, dip, sources_z=[0.0], snap_z=[0.4, 6.4], scale=1.5)
     assert np.array_equal(m.conn, m_again.conn) and np.array_equal(m.coords, m_again.coords)
+
+
+def test_conforming_3d_mesh_with_caliper_and_several_flushed_zones():
+    """A harder window: borehole radius varying with depth, two flushed zones of different radii, a thin bed, 45 degrees of
+    dip.  The mesher must stay valid (positive volumes, Dirichlet surface on the sphere) and keep the interfaces."""
+    R = 50.0
+    dip = np.deg2rad(45.0)
+    fg = np.array([[-90.0, -2.0, np.nan], [-2.0, -1.6, 0.35], [-1.6, 0.8, np.nan], [0.8, 3.0, 0.6], [3.0, 90.0, np.nan]])
+    bh = np.array([[-90.0, 0.10], [-3.0, 0.10], [-1.0, 0.14], [1.0, 0.11], [4.0, 0.12], [90.0, 0.12]])
+    cap = meshgen.LayerCap(np.concatenate([fg[:1, 0], fg[:, 1]]))
+    m = meshgen.make_mesh_3d_conforming(R, fg, bh, dip, sources_z=[0.0, 0.5], snap_z=[2.0, 2.5], scale=1.5, layer_cap=cap)
+    Q = m.coords[m.conn]
+    vol = np.abs(np.einsum("ij,ij->i", Q[:, 1] - Q[:, 0], np.cross(Q[:, 2] - Q[:, 0], Q[:, 3] - Q[:, 0]))) / 6.0
+    assert vol.min() > 0
+    # the thin bed caps the (r, z) size out to the boundary while the sector count is fixed: far elements are flat sheets,
+    # long in the angular direction only (where the field is smooth).  Near the tool the elements must stay well shaped.
+    edge = np.stack([np.sqrt(((Q[:, i] - Q[:, j]) ** 2).sum(1)) for i in range(4) for j in range(i + 1, 4)], 1)
+    qual = vol / np.sqrt((edge ** 2).mean(1)) ** 3 * (6 * np.sqrt(2))
+    near = np.sqrt((Q.mean(1) ** 2).sum(1)) < 5.0
+    assert near.sum() > 1000 and qual[near].min() > 5e-3
+    assert set(np.unique(m.mat)) == set(range(8))          # mud + 3 plain layers + 2 x (flushed, undisturbed)
+    rad = np.sqrt((m.coords ** 2).sum(1))
+    assert np.allclose(rad[m.bconn[m.bdirichlet == 1]], R, rtol=0, atol=1e-9) and rad.max() <= R * (1 + 1e-12)
+    assert meshgen.interface_straddlers(m, fg, bh, dip) <= 5e-3 * m.n_elems

@@ -57,25 +57,45 @@ def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice")
     return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=names)
 
 
-def cpu_baseline(work, rtol, budget_rhs=1):
-    """The oracle (scalar C port of the same algorithm) on the first batch, first RHS(s): assembly
-    + Jacobi-PCG + evaluation on ONE host core.  Reported beside the GPU number, never the target."""
-    from oracle.fem_oracle import solve_batch
-    w = work[0]
-    k = min(budget_rhs, len(w["sources"]))
-    src_ptr = [0]; sz = []; sI = []; ev_ptr = [0]; ez = []
-    for i in range(k):
-        z, I = w["sources"][i]
-        sz += list(z); sI += list(I); src_ptr.append(len(sz))
-        ez += list(w["evals"][i]); ev_ptr.append(len(ez))
+def cpu_baseline(work, rtol, cores=None):
+    """The oracle (scalar C port of the same algorithm) the way the reference farms its work out
+    (remo3d.py:592-595, worker.py:104-112: one single-threaded worker per core, every right-hand side
+    assembled and solved on its own): `cores` host threads, each running assembly + Jacobi-PCG +
+    evaluation of ONE right-hand side of the workload at the same time (the C calls release the GIL).
+    Reported beside the GPU number, never the target.  Returns (record, potentials of batch 0 / RHS 0)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.fem_oracle import lib, solve_batch
+    lib()                                            # compile / load outside the timed span
+    if cores is None:
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 16))
+    jobs = []
+    for bi, w in enumerate(work):
+        for ri in range(len(w["sources"])):
+            jobs.append((bi, ri))
+    jobs = jobs[:cores]
+
+    def one(job):
+        w = work[job[0]]
+        z, I = w["sources"][job[1]]
+        ez = list(w["evals"][job[1]])
+        out, rc, st = solve_batch(w["mesh"], w["sigma"], [0, len(z)], list(z), list(I), [0, len(ez)], ez, condense=True, rtol=rtol, maxit=1000)
+        return out, st["iterations"]
+
     t0 = time.time()
-    out, rc, st = solve_batch(w["mesh"], w["sigma"], src_ptr, sz, sI, ev_ptr, ez, condense=True, rtol=rtol, maxit=1000)
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        res = list(ex.map(one, jobs))
     dt = time.time() - t0
-    pts = sum(len(w["readers"][i]) for i in range(k))
-    return dict(value=pts / dt, unit="points/s", cores=1, kind="port",
-                sample=f"batch 0 of the workload, first {k} of {len(w['sources'])} right-hand sides ({pts} points): "
-                       f"oracle/fem_oracle.c assembly + Jacobi-PCG (rtol {rtol:g}, {st['iterations']} steps) in {dt:.1f} s; "
-                       "NGSolve is not installable here, so this is the build's scalar C restatement, not the reference binary"), out
+    pts = sum(len(work[bi]["readers"][ri]) for bi, ri in jobs)
+    its = [r[1] for r in res]
+    return dict(value=pts / dt, unit="points/s", cores=len(jobs), kind="port",
+                sample=f"the first {len(jobs)} right-hand sides of the workload ({pts} points), one per host thread at the same time, "
+                       f"each its own oracle/fem_oracle.c assembly + Jacobi-PCG (rtol {rtol:g}, {min(its)}-{max(its)} steps) + evaluation: "
+                       f"{dt:.1f} s wall; NGSolve is not installable here, so this is the build's scalar C restatement run one worker per "
+                       "core like the reference's farm, not the reference binary"), res[0][0]
 
 
 def pmc_traffic(workload, n_free, nnz):
@@ -112,6 +132,8 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip.h lists the keys)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket every k-th SpMV launch of a solve with HIP events (a bracket costs the stream ~1.5 us: bracketing "
@@ -124,6 +146,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     from remo3d_amd import solver, sweep, tasks
+    if args.tune:
+        from remo3d_amd import _lib
+        for kv in args.tune:
+            key, value = kv.split("=")
+            _lib.load().remo_debug_tune(int(key), int(value))
     dist_on = False
     if world > 1:
         import torch
@@ -220,6 +247,8 @@ def main():
                roofline=roofline,
                breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],
                                           eval=agg["ms_eval"], pcg_steps=int(agg["pcg_steps"]), mesh_generation_excluded_s=wl["mesh_s"]))
+    if args.tune:
+        out["config"]["debug_tune"] = list(args.tune)
     if not args.no_cpu:
         cb, ref_out = cpu_baseline(work, args.rtol)
         out["cpu_baseline"] = cb

@@ -399,30 +399,65 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
         if (g < pair_begin + npair) { pair = true; return pair_begin + 2 * (g - pair_begin); }
         return g + npair;
     };
-    const int64_t gstep = int64_t(gridDim.x) * rpb;
-    // xcd_windows: workgroups b, b + 8, ... share an XCD (and its L2); give them neighbouring row
-    // groups of every sweep step, so that an XCD gathers from one window of x instead of all of it
-    int vblock = int(blockIdx.x);
-    if (xcd_windows) {
-        const int per = int(gridDim.x >> 3), slot = int(blockIdx.x >> 3);
-        const int inner = (xcd_windows == 2 && (per & 31) == 0) ? (slot & 31) * (per >> 5) + (slot >> 5) : slot;   // 2: also CU-adjacent (probe)
-        vblock = int(blockIdx.x & 7) * per + inner;
+    // Row schedule.  Workgroups b, b + 8, ... share an XCD (and its L2).
+    //  xcd_windows 1: every sweep step of the chip is cut into 8 windows of neighbouring row groups, one per XCD
+    //    (an XCD gathers from one window of x per step, but over the launch it walks through all of x, three
+    //    times: vertex rows, edge rows, face rows);
+    //  xcd_windows >= 16: REGIONS.  The dofs of each class are in Morton order of the mesh, so the same fraction
+    //    of the vertex, edge and face rows covers the same part of space.  XCD j takes chunk j*nc .. j*nc + nc - 1
+    //    (nc = xcd_windows / 16) of all three classes, one chunk after the other, vertex, edge and face rows
+    //    of a chunk back to back: its L2 serves the three passes over a chunk's part of x from one fetch.
+    const int per = int(gridDim.x >> 3), slot = int(blockIdx.x >> 3), xcd = int(blockIdx.x & 7);
+    const int nchunk = xcd_windows >> 4;
+    const int64_t nface = n - pair_end;
+    // class sizes of one chunk, whole waves (4 lane groups of 16): waves stay uniform in the row class
+    const int64_t tc = int64_t(8) * (nchunk > 0 ? nchunk : 1);
+    const int64_t gran = 64 / LPR > 0 ? 64 / LPR : 1;
+    const int64_t sv = ((pair_begin + tc - 1) / tc + gran - 1) / gran * gran;
+    const int64_t se = ((npair + tc - 1) / tc + gran - 1) / gran * gran;
+    const int64_t sf = ((nface + tc - 1) / tc + gran - 1) / gran * gran;
+    const uint32_t S = uint32_t(sv + se + sf);
+    int64_t g, gstep, glimit;
+    if (nchunk > 0) {
+        g = int64_t(slot) * rpb + grp; gstep = int64_t(per) * rpb; glimit = int64_t(nchunk) * S;
+    } else {
+        int vblock = int(blockIdx.x);
+        if (xcd_windows) {
+            const int inner = (xcd_windows == 2 && (per & 31) == 0) ? (slot & 31) * (per >> 5) + (slot >> 5) : slot;   // 2: also CU-adjacent (probe)
+            vblock = xcd * per + inner;
+        }
+        g = int64_t(vblock) * rpb + grp; gstep = int64_t(gridDim.x) * rpb; glimit = ngroups;
     }
-    int64_t g = int64_t(vblock) * rpb + grp;
-    bool pair_n = false;
-    int64_t row_n = (g < ngroups) ? row_of(g, pair_n) : 0;
-    int32_t rs_n = (g < ngroups) ? rowptr[row_n] : 0, re_n = (g < ngroups) ? rowptr[row_n + 1] : 0;
-    for (; g < ngroups; g += gstep) {
+    // schedule position -> (row, pair); false: an empty slot of the last chunks
+    auto locate = [&](int64_t pos, int64_t &row, bool &pair) -> bool {
+        if (nchunk == 0) { row = row_of(pos, pair); return true; }
+        const uint32_t c = uint32_t(pos) / S, o = uint32_t(pos) - c * S;
+        const int64_t gc = int64_t(xcd) * nchunk + c;
+        pair = false;
+        if (o < uint32_t(sv)) { row = gc * sv + o; return row < pair_begin; }
+        if (o < uint32_t(sv + se)) { const int64_t e = gc * se + (o - uint32_t(sv)); pair = true; row = pair_begin + 2 * e; return e < npair; }
+        const int64_t f = gc * sf + (o - uint32_t(sv + se));
+        row = pair_end + f;
+        return f < nface;
+    };
+    bool pair_n = false, valid_n = false;
+    int64_t row_n = 0;
+    int32_t rs_n = 0, re_n = 0;
+    if (g < glimit) {
+        valid_n = locate(g, row_n, pair_n);
+        if (valid_n) { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
+    }
+    for (; g < glimit; g += gstep) {
         const int64_t row = row_n;
-        const bool pair = pair_n;
+        const bool pair = pair_n, valid = valid_n;
         const int32_t rs = rs_n, re = re_n;
         // the row pointers of the NEXT row are requested now: one of the three dependent round trips
         // of a row (pointers -> indices -> x) leaves the critical path
-        if (g + gstep < ngroups) {
-            row_n = row_of(g + gstep, pair_n);
-            rs_n = rowptr[row_n];
-            re_n = rowptr[row_n + 1];
+        if (g + gstep < glimit) {
+            valid_n = locate(g + gstep, row_n, pair_n);
+            if (valid_n) { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
         }
+        if (!valid) continue;
         T acc[2 * K];                             // [0, K): row, [K, 2K): row + 1
 #pragma unroll
         for (int c = 0; c < 2 * K; ++c) acc[c] = T(0);
@@ -560,8 +595,12 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     const int threads = spmm_threads();
     int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
-    // default row mapping of the pair kernel: XCD windows (measured 69 -> 60 us at 329k rows, k = 5)
-    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : 1;
+    // default row schedule of the pair kernel: XCD windows (measured 69 -> 60 us at 334k rows, k = 5); once the matrix no
+    // longer stays in the 256 MB of MALL between launches (3D, more than ~20 M stored entries), XCD regions of 4 chunks
+    // each: inside the solver loop (bench.py --tune 3=1 against 3=64 on one box) 152.7 -> 149.8 us at 716k rows,
+    // 490.8 -> 480.2 us at 2.17 M rows, but 58.6 -> 60.0 us at 289k rows (the stand-alone probe, tools/probe_regions.py,
+    // shows 2 ... 16 chunks within 1 % of each other)
+    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : ((lpr == 16 && A.nnz > 20000000) ? 64 : 1);
 #define REMO_SPMM(L)                                                                                                        \
     if (part)                                                                                                               \
         hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \

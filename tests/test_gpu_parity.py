@@ -73,6 +73,42 @@ def test_spmv_matches_oracle(which, k, mesh2d, mesh3d, gpu_ctx):
     b.close()
 
 
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_spmv_row_schedules_agree(k, mesh3d, gpu_ctx):
+    """The row schedules of the pair SpMM (remo_debug_tune key 3: 0 plain, 1 XCD windows, 16 * nc XCD regions of nc chunks; the
+    library picks regions only above 20 M stored entries, which no test mesh reaches) walk the rows in different orders but
+    sum every row the same way: results are bit-identical, also when chunks are nearly or completely empty (nc = 512), and a
+    solve under the region schedule gives the potentials of the default one."""
+    from remo3d_amd import _lib, solver
+    from oracle.fem_oracle import Oracle
+    L = _lib.load()
+    o = Oracle(mesh3d, SIGMA3, condense=True)
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC[:2], EVAL[:2])
+    try:
+        b.run(solver.make_opts(rtol=1e-9))
+        u_default = b.fetch()[0].copy()
+        x = np.random.default_rng(k).standard_normal((o.nfree, k))
+        xx = x if k > 1 else x[:, 0]
+        L.remo_debug_tune(0, 3)                                  # the pair kernel, whatever the heuristics say
+        L.remo_debug_tune(1, 16)
+        ref = None
+        for mapping in (1, 0, 16, 64, 16 * 37, 16 * 512):
+            L.remo_debug_tune(3, mapping)
+            y, _ = b.spmv(xx, reps=2)
+            if ref is None:
+                ref = y
+                yr = np.stack([o.spmv(x[:, c]) for c in range(k)], 1).reshape(ref.shape)
+                assert np.max(np.abs(ref - yr)) <= 5e-12 * np.max(np.abs(yr))
+            assert np.array_equal(y, ref), mapping
+        L.remo_debug_tune(3, 64)
+        b.run(solver.make_opts(rtol=1e-9))
+        assert np.max(np.abs(b.fetch()[0] - u_default)) <= 1e-9 * np.max(np.abs(u_default))
+    finally:
+        for key, v in ((0, 0), (1, 0), (3, -1)):
+            L.remo_debug_tune(key, v)
+        b.close()
+
+
 @pytest.mark.parametrize("precision", ["fp64", "mixed"])
 def test_more_rhs_than_one_chunk(precision, mesh2d, gpu_ctx):
     """11 right-hand sides -> chunks of 8 + 3; every column must equal its single-RHS solve (in the mixed

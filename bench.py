@@ -249,7 +249,7 @@ def main():
                                           eval=agg["ms_eval"], pcg_steps=int(agg["pcg_steps"]), mesh_generation_excluded_s=wl["mesh_s"]))
     if args.tune:
         out["config"]["debug_tune"] = list(args.tune)
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:           # the CPU leg belongs to the N = 1 line only
         cb, ref_out = cpu_baseline(work, args.rtol)
         out["cpu_baseline"] = cb
         got = resident[0].fetch()[0]

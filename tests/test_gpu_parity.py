@@ -339,3 +339,38 @@ def test_ragged_and_degenerate_right_hand_sides(precision, mesh2d, gpu_ctx):
     assert outs[1].size == 0
     assert np.all(outs[2] == 0.0)
     assert np.allclose(outs[3], [ref[0][2], ref[0][0]], rtol=1e-8, atol=0) and np.isfinite(outs[3][0]) and outs[3][0] > outs[3][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_full_size_batch_properties(precision, gpu_ctx):
+    """The headline workload at its full size (bench.py size S: BM3, dip 30 degrees, ~63 k tetrahedra, ~290 k unknowns, 14 M
+    stored entries) through properties that need no second solver: reciprocity u_a(z_b) = u_b(z_a) of the symmetric operator,
+    linearity in the source strengths (dipole = difference of its poles), scaling of all conductivities by c (u -> u / c),
+    and the two-level and the Jacobi preconditioner agreeing on the solution.  The oracle checks one right-hand side
+    of the same batch (a few seconds on one core)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from remo3d_amd import solver
+    from oracle.fem_oracle import solve_batch as oracle_batch
+    w = bench.build_workload(0, 1, 5, bench.SIZES["S"])["work"][0]
+    mesh, sigma = w["mesh"], np.asarray(w["sigma"], dtype=np.float64)
+    za, zb, zc = 0.0, 0.4, 6.4
+    src = [([za], [1.0]), ([zb], [1.0]), ([za, zb], [1.0, -1.0]), ([za], [2.5])]
+    ev = [[zb, zc], [za, zc], [zc, 2.0], [zb, zc]]
+    opts = solver.make_opts(rtol=1e-11, precision=precision, maxsteps=3000)
+    out, st, rc = gpu_ctx.solve_batch(mesh, sigma, src, ev, opts)
+    assert rc == 0 and st["n_free"] > 250000 and st["nnz"] > 12000000, st
+    tol = 2e-8
+    assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0])                               # reciprocity
+    assert abs(out[2][0] - (out[0][1] - out[1][1])) <= tol * abs(out[0][1])                 # linearity: dipole at z_c
+    assert np.allclose(out[3], 2.5 * out[0], rtol=tol, atol=0)                              # strength scaling
+    out_c, _, rc = gpu_ctx.solve_batch(mesh, 4.0 * sigma, src[:1], ev[:1], opts)
+    assert rc == 0 and np.allclose(out_c[0], out[0] / 4.0, rtol=tol, atol=0)                # conductivity scaling
+    out_j, st_j, rc = gpu_ctx.solve_batch(mesh, sigma, src[:1], ev[:1], solver.make_opts(preconditioner="local", rtol=1e-11, precision=precision, maxsteps=5000))
+    assert rc == 0 and np.allclose(out_j[0], out[0], rtol=tol, atol=0)
+    ref, rc_o, st_o = oracle_batch(mesh, sigma, [0, 1], [za], [1.0], [0, 2], [zb, zc], condense=True, rtol=1e-11, maxit=5000)
+    assert rc_o == 0 and st_o["n"] == st["n_free"] and st_o["nnz"] == st["nnz"]
+    assert np.allclose(out[0], ref, rtol=tol, atol=0), (out[0], ref)

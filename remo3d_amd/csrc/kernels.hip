@@ -778,8 +778,10 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 // One Chebyshev step on the vertex block, 8 lanes per row:
 //   z += d;  res -= A_vv d;  d' = c1 d + c2 D^-1 res
 // FIRST: z = 0, res = r, d = D^-1 r / theta are formed on the fly from the PCG residual (no set-up
-// pass); LAST: d' is skipped and the <r, z> partial sums are left for the PCG scalars.
-template <class T, int K, bool FIRST, bool LAST>
+// pass).  LAST = 1 (degree 1 only): z = d, nothing else.  LAST = 2: the polynomial's last term needs no
+// product of its own (z_final = z + d + d'), so the launch that forms d' also finishes z and leaves the
+// <r, z> partial sums for the PCG scalars: a polynomial of `degree` terms costs degree - 1 launches.
+template <class T, int K, bool FIRST, int LAST>
 __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const T *__restrict__ val, const T *__restrict__ dinv,
                                                    const T *__restrict__ d_old, T *__restrict__ d_new,
@@ -821,12 +823,14 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
         TReduce<K, LPR>::run(t, sub);
         if (mine) {
             const T dold = FIRST ? di * rr * inv_theta : dold_in;
-            const T zi = FIRST ? dold : z_in + dold;
+            T zi = FIRST ? dold : z_in + dold;
             const T ri = (FIRST ? rr : res_in) - t[0];
+            const T dn = c1 * dold + c2 * di * ri;
+            if (LAST == 2) zi += dn;
             z[at] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
             if (!LAST) {
                 res[at] = ri;
-                d_new[at] = c1 * dold + c2 * di * ri;
+                d_new[at] = dn;
             }
             if (LAST) dot += double(rr) * double(zi);
         }
@@ -1200,20 +1204,21 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
     double rho = 1.0 / sig;
     const int g = cheb_grid(b.nv_coarse);
     double *part = part_slot + int64_t(b.nb_vec) * k;
-    for (int j = 0; j < b.cheb_degree; ++j) {
+    const int launches = b.cheb_degree > 1 ? b.cheb_degree - 1 : 1;   // the last term rides on the launch before it
+    for (int j = 0; j < launches; ++j) {
         const double rho_new = 1.0 / (2.0 * sig - rho);
         const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
         rho = rho_new;
         const T *dold = b.cd[j & 1];
         T *dnew = b.cd[(j + 1) & 1];
-        const bool first = (j == 0), last = (j + 1 == b.cheb_degree);
+        const bool first = (j == 0), last = (j + 1 == launches);
 #define REMO_CHEB(F, L)                                                                                                                             \
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
                                         b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0))
-        if (first && last) { REMO_CHEB(true, true); }
-        else if (first) { REMO_CHEB(true, false); }
-        else if (last) { REMO_CHEB(false, true); }
-        else { REMO_CHEB(false, false); }
+        if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
+        else if (first) { REMO_CHEB(true, 0); }
+        else if (last) { REMO_CHEB(false, 2); }
+        else { REMO_CHEB(false, 0); }
 #undef REMO_CHEB
     }
 }

@@ -176,7 +176,8 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
  * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;
  * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
  * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
- * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row.  Process-global. */
+ * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
+ * Chebyshev step as a launch of its own instead of inside the update launch.  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -64,6 +64,7 @@ void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, 
 
 int spmv_grid(int64_t n, int lanes_per_row);
 int vec_grid(int64_t n);
+void set_fold_first(int v);                 // 1 (default): FIRST Chebyshev step inside the update launch
 void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 threads, 3 mapping, 4 grid (0 = default)
 int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>

@@ -555,6 +555,8 @@ struct SpmmTuning {
     int grid = 0;
 };
 static SpmmTuning g_tune;
+static int g_fold_first = 1;   // remo_debug_tune key 9: FIRST Chebyshev step inside the update launch (0 = own launch)
+void set_fold_first(int v) { g_fold_first = v; }
 void set_spmm_tuning(int key, int value) {
     switch (key) {
         case 0: g_tune.variant = value; break;
@@ -674,6 +676,14 @@ template <class T> struct ChebArgsT {
     T *z, *res;       // [nv][K] polynomial value so far / residual of the vertex block system
     T *d0;            // [nv][K] first Chebyshev direction
 };
+// FIRST Chebyshev step folded into the update launch (k_pcg_update): nb_flat = 0 switches it off
+template <class T> struct FoldArgsT {
+    int nb_flat = 0;             // workgroups [0, nb_flat) do the flat update of the rows >= nv, the rest the vertex rows
+    const int32_t *rowptr = nullptr, *col = nullptr;
+    const T *val = nullptr;
+    T *d_new = nullptr, *stage = nullptr;
+    double c1 = 0.0, c2 = 0.0;
+};
 // All PCG kernels are templates on the storage type T of matrix values and vectors: double = the
 // product path, float = the inner solver of the mixed-precision mode (BASELINE config 5).  Scalars,
 // partial sums and the convergence test are double in both.
@@ -712,7 +722,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const T *__restrict__ p,
                                                     const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
-                                                    const T *__restrict__ dinv) {
+                                                    const T *__restrict__ dinv, FoldArgsT<T> fold) {
     // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
@@ -756,8 +766,60 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         }
         return;
     }
+    // fold.nb_flat > 0: the workgroups behind the first nb_flat take the vertex rows, 8 lanes per row, and run the FIRST
+    // Chebyshev step on them in the same pass (its operand D^-1 (r - alpha q) / theta is formed per gathered entry from
+    // the OLD r and q, both complete at this point).  The new vertex residual goes to a staging vector (fold.stage =
+    // the free one of the two direction buffers): r itself is still being gathered by the neighbours' rows; the next
+    // Chebyshev launch commits it.  One launch less per PCG step.
+    const int nb_flat = fold.nb_flat > 0 ? fold.nb_flat : int(gridDim.x);
+    if (int(blockIdx.x) >= nb_flat) {
+        constexpr int LPR = 8, RPB = 256 / LPR;
+        static_assert(K <= LPR, "one column per lane after the transposing reduction");
+        const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+        int idx[K], own[K];
+        towner_init<K, LPR>(idx, own, sub);
+        const int mycol = idx[0];
+        const bool mine = own[0] != 0;
+        const T inv_theta = T(ch.inv_theta), c1 = T(fold.c1), c2 = T(fold.c2);
+        T al[K], a_mine = T(0);
+#pragma unroll
+        for (int c = 0; c < K; ++c) { al[c] = T(alpha[c]); a_mine = (c == mycol) ? al[c] : a_mine; }
+        const int64_t nv = ch.nv;
+        for (int64_t row = int64_t(int(blockIdx.x) - nb_flat) * RPB + grp; row < nv; row += int64_t(int(gridDim.x) - nb_flat) * RPB) {
+            const int32_t rs = fold.rowptr[row], re = fold.rowptr[row + 1];
+            const int64_t at = row * K + mycol;
+            T di = T(0), rn = T(0);
+            if (mine) {
+                di = dinv[row];
+                x[at] += a_mine * p[at];
+                rn = r[at] - a_mine * q[at];
+            }
+            T t[K];
+#pragma unroll
+            for (int c = 0; c < K; ++c) t[c] = T(0);
+            for (int32_t pp = rs + sub; pp < re; pp += LPR) {
+                const int32_t j = fold.col[pp];
+                if (j >= nv) break;  // columns ascend: the vertex block leads the row
+                const T v = fold.val[pp] * dinv[j] * inv_theta;
+                const T *rj = r + int64_t(j) * K, *qj = q + int64_t(j) * K;
+#pragma unroll
+                for (int c = 0; c < K; ++c) t[c] += v * (rj[c] - al[c] * qj[c]);
+            }
+            TReduce<K, LPR>::run(t, sub);
+            if (mine) {
+                const T dold = di * rn * inv_theta;
+                const T ri = rn - t[0];
+                ch.z[at] = dold;
+                ch.res[at] = ri;
+                fold.d_new[at] = c1 * dold + c2 * di * ri;
+                fold.stage[at] = rn;
+            }
+        }
+        return;
+    }
+    const int64_t i0 = fold.nb_flat > 0 ? ch.nv : 0;
 #pragma unroll 2
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+    for (int64_t i = i0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(nb_flat) * blockDim.x) {
         const T d = dinv[i];
         const bool coarse = i < ch.nv;
 #pragma unroll
@@ -786,7 +848,7 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
                                                    const T *__restrict__ val, const T *__restrict__ dinv,
                                                    const T *__restrict__ d_old, T *__restrict__ d_new,
                                                    T *__restrict__ z, T *__restrict__ res, double c1_, double c2_, double inv_theta_,
-                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
+                                                   T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit) {
     const T c1 = T(c1_), c2 = T(c2_), inv_theta = T(inv_theta_);
     constexpr int LPR = 8, RPB = 256 / LPR;
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
@@ -806,7 +868,12 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
         T di = T(0), rr = T(0), dold_in = T(0), z_in = T(0), res_in = T(0);
         if (mine) {
             di = dinv[row];
-            rr = r[at];
+            if (commit) {   // the update launch ran the FIRST step and left the new vertex residual in d_new (free until this
+                rr = d_new[at];   // launch writes it): r could not take it while the neighbours' rows were still gathering r
+                r[at] = rr;
+            } else {
+                rr = r[at];
+            }
             if (!FIRST) { dold_in = d_old[at]; z_in = z[at]; res_in = res[at]; }
         }
         T t[K];
@@ -1165,7 +1232,13 @@ template <class T> static ChebArgsT<T> cheb_args(const PcgBuffersT<T> &b) {
 
 // C r for the vertex block: `degree` Chebyshev steps; the last one leaves the <r_v, z_v> partials
 // behind the nb_vec partials of the high-order part (slot = even / odd step buffer)
-template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s) {
+// the update launch can take the FIRST step along when the polynomial has launches of its own left to commit the
+// vertex residual (degree >= 3) and is not applied through the squared block (2D)
+template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b) {
+    return g_fold_first && b.cheb_degree >= 3 && b.nv_coarse > 0 && !(b.sq_rowptr && (b.cheb_degree & 1) == 0);
+}
+
+template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s, bool first_done = false) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
     if (b.sq_rowptr && (b.cheb_degree & 1) == 0) {   // two Richardson factors of the Chebyshev polynomial per launch
         const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
@@ -1212,9 +1285,11 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
         const T *dold = b.cd[j & 1];
         T *dnew = b.cd[(j + 1) & 1];
         const bool first = (j == 0), last = (j + 1 == launches);
+        if (first && first_done) continue;        // k_pcg_update did it (with the c1, c2 of cheb_first_coefficients)
+        const int commit = (first_done && j == 1) ? 1 : 0;
 #define REMO_CHEB(F, L)                                                                                                                             \
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
-                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0))
+                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit))
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
         else if (last) { REMO_CHEB(false, 2); }
@@ -1241,9 +1316,20 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<T> ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
-    launch_cheb(A, k, b, nxt, s);
+    FoldArgsT<T> fold;
+    int grid = g;
+    const bool folded = cheb_first_folds(b);
+    if (folded) {
+        const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
+        const double sig = theta / delta, rho = 1.0 / sig, rho_new = 1.0 / (2.0 * sig - rho);
+        fold.nb_flat = g; fold.rowptr = A.rowptr; fold.col = A.col; fold.val = A.val;
+        fold.d_new = b.cd[1]; fold.stage = b.cd[0];
+        fold.c1 = rho_new * rho; fold.c2 = 2.0 * rho_new / delta;      // the j = 0 coefficients of launch_cheb
+        grid = g + cheb_grid(b.nv_coarse);
+    }
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold));
+    launch_cheb(A, k, b, nxt, s, folded);
 }
 
 // Residual replacement of the mixed mode, in place of launch_pcg_update at the chosen steps:
@@ -1281,7 +1367,7 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<float> ch = cheb_args(b);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv));
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>()));
     launch_mixed_accumulate(n * k, x64, b.x, 1, s);
     launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0));

@@ -869,6 +869,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     if (key == 6) g_square = value;
     else if (key == 7) g_sq_lanes = value;
     else if (key == 8) set_symbolic_tuning(value);
+    else if (key == 9) set_fold_first(value);
     else set_spmm_tuning(key, value);
 }
 

@@ -532,9 +532,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.nv_coarse = two_level ? sy.nvfree : 0;
         // Defaults from GPU scans (tools/scan_coarse2d.py, scan_coarse3d.py).  3D: the best degree / interval grow with the
         // vertex count (kappa of the P1 block ~ nv^(2/3), degree ~ sqrt(kappa)): (5, 90) at 12.6 k vertices, (8-10, 150-200) at
-        // 24 k, (12-16, 300-600) at 80 k.  2D (launch-bound steps, paired Chebyshev launches): (16, 600).
+        // 24 k, (12-16, 300-600) at 80 k; fine scan after the first / last step lost their launches (tools/scan_coarse3d_fine.py):
+        // (5, 70-90) at 12.8 k, (8, 120-160) at 27 k (7: +3 %, 9: +4.5 %).  2D (launch-bound steps, paired Chebyshev launches): (16, 600).
         const double nv_rel = double(sy.nvfree > 0 ? sy.nvfree : 1) / 12600.0;
-        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.5)))) : 16;
+        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.9)))) : 16;
         const double ratio_default = (dim == 3) ? std::min(1200.0, std::max(60.0, 90.0 * std::pow(nv_rel, 2.0 / 3.0))) : 600.0;
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : deg_default) : 0;
         buf.cheb_lmax = buf.cheb_lmin = 0.0;

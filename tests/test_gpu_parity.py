@@ -374,3 +374,32 @@ def test_full_size_batch_properties(precision, gpu_ctx):
     ref, rc_o, st_o = oracle_batch(mesh, sigma, [0, 1], [za], [1.0], [0, 2], [zb, zc], condense=True, rtol=1e-11, maxit=5000)
     assert rc_o == 0 and st_o["n"] == st["n_free"] and st_o["nnz"] == st["nnz"]
     assert np.allclose(out[0], ref, rtol=tol, atol=0), (out[0], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_chebyshev_launch_folds_keep_the_preconditioner(precision, mesh3d, gpu_ctx):
+    """The first Chebyshev step rides on the update launch for degree >= 3 (remo_debug_tune key 9, default on) and the last
+    term on the launch before it for degree >= 2: the same polynomial, so the same potentials and (up to rounding in the
+    first operand, formed per gathered entry instead of from the stored residual) the same step counts as with one launch per
+    step; degrees 1 and 2 take the unfolded route."""
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        ref = None
+        for degree in (1, 2, 3, 4, 7):
+            res = {}
+            for fold in (0, 1):
+                L.remo_debug_tune(9, fold)
+                rc = b.run(solver.make_opts(rtol=1e-10, coarse_degree=degree, coarse_ratio=30, precision=precision))
+                assert rc == 0
+                res[fold] = (np.concatenate(b.fetch()), b.stats["pcg_steps"])
+            assert np.allclose(res[0][0], res[1][0], rtol=1e-8, atol=0), degree
+            assert abs(res[0][1] - res[1][1]) <= max(2, res[0][1] // 50), (degree, res[0][1], res[1][1])
+            if ref is None:
+                ref = res[1][0]
+            assert np.allclose(res[1][0], ref, rtol=1e-7, atol=0), degree
+    finally:
+        L.remo_debug_tune(9, 1)
+        b.close()

@@ -242,7 +242,7 @@ def main():
                config=dict(workload=workload_name,
                            batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
                            mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=len(ctxs), preconditioner="multigrid = Chebyshev (degree 5 on lmax/90..lmax at this size) on the P1 vertex block + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=len(ctxs), preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
                            batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline,
                breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],

@@ -102,7 +102,7 @@ def pmc_traffic(workload, n_free, nnz):
     """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this exact workload
     (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic_default_bench.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic_default_bench.json")) as f:
             p = json.load(f)
     except OSError:
         return None
@@ -235,7 +235,7 @@ def main():
                     avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,
                     empty_event_pair_us=1e3 * agg.get("ev_over", 0.0),
-                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if args.precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_e_pmc_traffic_default_bench.json")
+                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if args.precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_f_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f64" if args.precision == "fp64" else "f32 PCG inside f64 residual refinement", data="synthetic",

@@ -126,6 +126,23 @@ def test_more_rhs_than_one_chunk(precision, mesh2d, gpu_ctx):
         assert np.allclose(outs[i], single[0], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_full_chunk_of_eight_with_the_two_level_preconditioner_in_3d(precision, mesh3d, gpu_ctx):
+    """9 right-hand sides on a 3D mesh -> a chunk of 8 (the widest instantiation of every PCG kernel, including the update
+    launch that carries the first Chebyshev step) and a chunk of 1: every column equals its single-RHS solve."""
+    from remo3d_amd import solver
+    zs = np.linspace(-0.4, 0.4, 9)
+    src = [([z], [1.0]) for z in zs]
+    ev = [[z + 0.4, z + 6.4] for z in zs]
+    opts = solver.make_opts(preconditioner="multigrid", rtol=1e-11, maxsteps=5000, precision=precision)
+    outs, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, opts)
+    assert rc == 0
+    for i in (0, 4, 7, 8):
+        single, _, rc1 = gpu_ctx.solve_batch(mesh3d, SIGMA3, [src[i]], [ev[i]], opts)
+        assert rc1 == 0
+        assert np.allclose(outs[i], single[0], rtol=1e-8, atol=0), i
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_homogeneous_medium_gives_true_resistivity(dim, gpu_ctx):
     """Physics identity of remo3d.py:285-306: in a homogeneous medium Ra == R for every tool."""

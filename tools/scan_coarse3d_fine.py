@@ -14,7 +14,7 @@ if __name__ == "__main__":
     wl = bench.build_workload(0, 1, 20, bench.SIZES[size])
     ctx = solver.Context(0)
     bs = [ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for w in wl["work"]]
-    grid = [(0, 0)] + [(d, r) for d in ((5, 6, 7, 8) if size == "S" else (7, 8, 9, 10, 12)) for r in ((70, 90, 120, 160) if size == "S" else (120, 160, 220, 300))]
+    grid = [(0, 0)] + [(d, r) for d in ((3, 4, 5, 6, 7, 8) if size == "S" else (6, 7, 8, 9, 10, 12)) for r in ((40, 60, 90, 120, 160) if size == "S" else (90, 120, 160, 220, 300))]
     for rnd in range(2):
         for deg, ratio in grid:
             steps = 0; ms = 0.0

@@ -1289,8 +1289,13 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
         const bool first = (j == 0), last = (j + 1 == launches);
         if (first && first_done) continue;        // k_pcg_update did it (with the c1, c2 of cheb_first_coefficients)
         const int commit = (first_done && j == 1) ? 1 : 0;
+        // only the launch that leaves partial sums is tied to the cheb_grid slots; the others take one row group per
+        // workgroup slot (at 83 k vertices 512 workgroups walk five row groups each, a chain of five dependent round trips:
+        // 17.9 us per launch under rocprofv3, profiles/r01_f_kernel_stats_sizeL_10depths.csv)
+        const int64_t g_rows = (b.nv_coarse + 31) / 32;
+        const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
 #define REMO_CHEB(F, L)                                                                                                                             \
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(g), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
                                         b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit))
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
@@ -1327,7 +1332,7 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
         fold.nb_flat = g; fold.rowptr = A.rowptr; fold.col = A.col; fold.val = A.val;
         fold.d_new = b.cd[1]; fold.stage = b.cd[0];
         fold.c1 = rho_new * rho; fold.c2 = 2.0 * rho_new / delta;      // the j = 0 coefficients of launch_cheb
-        grid = g + cheb_grid(b.nv_coarse);
+        grid = g + int((b.nv_coarse + 31) / 32);   // the vertex workgroups leave no partial sums: one row group each
     }
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold));

@@ -1291,7 +1291,7 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
         const int commit = (first_done && j == 1) ? 1 : 0;
         // only the launch that leaves partial sums is tied to the cheb_grid slots; the others take one row group per
         // workgroup slot (at 83 k vertices 512 workgroups walk five row groups each, a chain of five dependent round trips:
-        // 17.9 us per launch under rocprofv3, profiles/r01_f_kernel_stats_sizeL_10depths.csv)
+        // 17.9 us per launch under rocprofv3, profiles/r01_f_kernel_stats_sizeL_10depths_before_grid_fix.csv; after: 14.2 us, …_after_grid_fix.csv)
         const int64_t g_rows = (b.nv_coarse + 31) / 32;
         const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
 #define REMO_CHEB(F, L)                                                                                                                             \

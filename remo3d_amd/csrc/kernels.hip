@@ -938,14 +938,37 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
 #pragma unroll
             for (int c = 0; c < K; ++c) scal[16 + 8 * ((step + 1) & 1) + c] = rzn[c];   // read by the next update launch
     }
-#pragma unroll 2
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const T d = dinv[i];
-        const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
+    // U rows per thread are loaded before any of them is stored: p is read and written through the same pointer, and a store
+    // of one row otherwise holds back the loads of the next (one row in flight per thread: 2.7 TB/s at 5.4 M rows in fp32)
+    constexpr int U = 4;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
+        T d[U], zv[U][K], pv[U][K];
 #pragma unroll
-        for (int c = 0; c < K; ++c) {
-            const T zi = d * src[i * K + c];
-            p[i * K + c] = first ? zi : zi + T(beta[c]) * p[i * K + c];
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            d[u] = T(0);
+#pragma unroll
+            for (int c = 0; c < K; ++c) { zv[u][c] = T(0); pv[u][c] = T(0); }
+            if (i < n) {
+                d[u] = dinv[i];
+                const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
+#pragma unroll
+                for (int c = 0; c < K; ++c) zv[u][c] = src[i * K + c];
+                if (!first)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) pv[u][c] = p[i * K + c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n)
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const T zi = d[u] * zv[u][c];
+                    p[i * K + c] = first ? zi : zi + T(beta[c]) * pv[u][c];
+                }
         }
     }
 }

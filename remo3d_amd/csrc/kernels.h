@@ -35,6 +35,10 @@ template <class T> struct PcgBuffersT {
     const int32_t *sq_rowptr = nullptr, *sq_col = nullptr;
     const T *sq_a = nullptr, *sq_b = nullptr;
     int sq_lanes = 16;      // lanes per row of the paired kernel (8 / 16 / 32 by the average row length of B)
+    // compact copy of the vertex block (launch_vblock_compact): inside the full matrix a vertex row's ~15 leading entries sit
+    // in a row of ~110, so a Chebyshev launch touches three partly used cache lines per row; nullptr -> read A in place
+    const int32_t *vb_rowptr = nullptr, *vb_col = nullptr;
+    const T *vb_val = nullptr;
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
@@ -85,6 +89,10 @@ int cheb_grid(int64_t nv);
 
 // mixed precision: conversions around the fp32 inner solve
 void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s);
+// compact CSR copy of the leading nv x nv block of A (columns ascend, so the block's entries lead every row); *flag is raised
+// when it does not fit `capacity` entries; vb_rowptr[nv] = entries
+void launch_vblock_compact(int64_t nv, const CsrView &A, int32_t *vb_rowptr, int32_t *vb_col, double *vb_val, int64_t capacity, int32_t *flag,
+                           hipStream_t s);
 void launch_mixed_residual(int64_t n, const double *f, const double *q /* may be null */, float *r32, hipStream_t s);
 void launch_mixed_accumulate(int64_t n, double *x, float *e, int zero_e, hipStream_t s);
 // one PCG step's update with residual replacement (x32 += alpha p; x64 += x32; r32 = f - A64 x64; C r)

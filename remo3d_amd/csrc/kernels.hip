@@ -1130,6 +1130,36 @@ __global__ void __launch_bounds__(1024) k_scan_counts(int64_t n, const int32_t *
     for (int64_t i = b; i < e; ++i) { out[i] = int32_t(run < INT_MAX ? run : INT_MAX); run += cnt[i]; }
 }
 
+// compact copy of the vertex block: PASS 0 counts the leading entries (column < nv) of every vertex row, PASS 1 copies them
+template <int PASS>
+__global__ void __launch_bounds__(256) k_vblock_compact(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        const double *__restrict__ val, int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ vb_rowptr, int32_t *__restrict__ vb_col,
+                                                        double *__restrict__ vb_val, int64_t capacity, int32_t *flag) {
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= nv) return;
+    const int32_t rs = rowptr[row], re = rowptr[row + 1];
+    if (PASS == 0) {
+        cnt[row] = lower_bound_col(col, rs, re, int32_t(nv)) - rs;
+    } else {
+        const int32_t at = vb_rowptr[row], len = vb_rowptr[row + 1] - at;
+        if (int64_t(at) + len > capacity) { if (len > 0) atomicOr(flag, 1); return; }
+        for (int32_t e = 0; e < len; ++e) { vb_col[at + e] = col[rs + e]; vb_val[at + e] = val[rs + e]; }   // vertex rows are plain CSR
+    }
+}
+
+void launch_vblock_compact(int64_t nv, const CsrView &A, int32_t *vb_rowptr, int32_t *vb_col, double *vb_val, int64_t capacity, int32_t *flag,
+                           hipStream_t s) {
+    if (nv <= 0) return;
+    const int g = int((nv + 255) / 256);
+    int32_t *cnt = vb_col;   // the counts live in the (not yet used) column array: capacity >= nv is required by the caller
+    hipLaunchKernelGGL((k_vblock_compact<0>), dim3(g), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, cnt, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (double *)nullptr, capacity, flag);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, nv, cnt, vb_rowptr);
+    hipLaunchKernelGGL((k_vblock_compact<1>), dim3(g), dim3(256), 0, s, nv, A.rowptr, A.col, A.val, (int32_t *)nullptr, vb_rowptr, vb_col, vb_val,
+                       capacity, flag);
+}
+
 void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int32_t *sq_rowptr, int32_t *sq_col, double *sq_a, double *sq_b,
                           int64_t capacity, int32_t *flag, hipStream_t s) {
     if (nv <= 0) return;
@@ -1303,6 +1333,8 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
     const int g = cheb_grid(b.nv_coarse);
     double *part = part_slot + int64_t(b.nb_vec) * k;
     const int launches = b.cheb_degree > 1 ? b.cheb_degree - 1 : 1;   // the last term rides on the launch before it
+    const int32_t *vrow = b.vb_rowptr ? b.vb_rowptr : A.rowptr, *vcol = b.vb_rowptr ? b.vb_col : A.col;   // compact vertex block if there is one
+    const T *vval = b.vb_rowptr ? b.vb_val : A.val;
     for (int j = 0; j < launches; ++j) {
         const double rho_new = 1.0 / (2.0 * sig - rho);
         const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
@@ -1318,7 +1350,7 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
         const int64_t g_rows = (b.nv_coarse + 31) / 32;
         const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
 #define REMO_CHEB(F, L)                                                                                                                             \
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, A.rowptr, A.col, A.val, b.dinv, dold, dnew, \
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, vval, b.dinv, dold, dnew, \
                                         b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit))
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
@@ -1352,7 +1384,8 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     if (folded) {
         const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
         const double sig = theta / delta, rho = 1.0 / sig, rho_new = 1.0 / (2.0 * sig - rho);
-        fold.nb_flat = g; fold.rowptr = A.rowptr; fold.col = A.col; fold.val = A.val;
+        fold.nb_flat = g;
+        fold.rowptr = b.vb_rowptr ? b.vb_rowptr : A.rowptr; fold.col = b.vb_rowptr ? b.vb_col : A.col; fold.val = b.vb_rowptr ? b.vb_val : A.val;
         fold.d_new = b.cd[1]; fold.stage = b.cd[0];
         fold.c1 = rho_new * rho; fold.c2 = 2.0 * rho_new / delta;      // the j = 0 coefficients of launch_cheb
         grid = g + int((b.nv_coarse + 31) / 32);   // the vertex workgroups leave no partial sums: one row group each

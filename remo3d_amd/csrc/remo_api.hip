@@ -132,6 +132,8 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
+int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
+constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
 // fp64 side of a mixed-precision inner solve: where the residual replacements read and write
 struct RefineHooks {
@@ -501,6 +503,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
+        need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;
         if (o.precision == 1)
@@ -589,7 +592,14 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         double *sq_a = nullptr, *sq_b = nullptr;
         // paired steps pay off where B stays small: 2D (~19 entries per row: 81 vs 93 us per PCG step); in 3D B has ~65
         // entries per row and three launches on it cost more than six on A_vv (153 vs 149 us) - forced by tune value 2
+        // compact copy of the vertex block for the Chebyshev launches (remo_debug_tune key 13: 0 = read A in place)
+        int32_t h_vb[2] = {1, 0};   // flag, entries
+        int32_t *vb_rowptr = nullptr, *vb_col = nullptr;
+        double *vb_val = nullptr;
         const bool want_square = two_level && (buf.cheb_degree % 2 == 0) && ((g_square == 1 && dim == 2) || g_square == 2);
+        // measured in the bench (--tune 13=0 against 13=1, one box): 538.9 -> 516.1 ms solve per step at 83 k vertices; at 12.8 k the
+        // launches are latency, not bytes (714 -> 710 ms) and building the copy costs what it saves: larger blocks only (2 forces it)
+        const bool want_compact = two_level && !want_square && (g_compact == 2 || (g_compact == 1 && buf.nv_coarse > 16384));
         if (two_level) {  // spectrum bound of the Jacobi-scaled vertex block for the Chebyshev interval
             HIP_TRY(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long), s));
             launch_vblock_bound(buf.nv_coarse, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, d_dinv, d_bound, s);
@@ -606,8 +616,20 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             HIP_TRY(hipMemcpyAsync(&h_sq[0], d_sqflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&h_sq[1], sq_rowptr + nvc, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
+        if (want_compact) {
+            const int64_t nvc = buf.nv_coarse, cap = (nvc + 64) * kCompactPerRow;
+            vb_rowptr = ctx->take<int32_t>(size_t(nvc) + 2);
+            vb_col = ctx->take<int32_t>(size_t(cap));
+            vb_val = ctx->take<double>(size_t(cap));
+            int32_t *d_vbflag = ctx->take<int32_t>(1);
+            HIP_TRY(hipMemsetAsync(d_vbflag, 0, sizeof(int32_t), s));
+            launch_vblock_compact(nvc, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, vb_rowptr, vb_col, vb_val, cap, d_vbflag, s);
+            HIP_TRY(hipMemcpyAsync(&h_vb[0], d_vbflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&h_vb[1], vb_rowptr + nvc, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (want_compact && h_vb[0] == 0 && h_vb[1] > 0) { buf.vb_rowptr = vb_rowptr; buf.vb_col = vb_col; buf.vb_val = vb_val; }
         if (two_level) {
             double lmax;
             std::memcpy(&lmax, &h_bound, sizeof lmax);
@@ -659,6 +681,11 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             f.cd[0] = ctx->take<float>(nc); f.cd[1] = ctx->take<float>(nc);
             f.progress = buf.progress; f.progress_len = buf.progress_len;
             f.nb_spmv = buf.nb_spmv; f.nb_vec = buf.nb_vec;
+            if (buf.vb_rowptr) {
+                float *vb32 = ctx->take<float>(size_t(h_vb[1]) + 1);
+                launch_to_float(h_vb[1], buf.vb_val, vb32, s);
+                f.vb_rowptr = buf.vb_rowptr; f.vb_col = buf.vb_col; f.vb_val = vb32;
+            }
             if (buf.sq_rowptr) {
                 float *a32 = ctx->take<float>(size_t(h_sq[1]) + 1), *b32 = ctx->take<float>(size_t(h_sq[1]) + 1);
                 launch_to_float(h_sq[1], buf.sq_a, a32, s);
@@ -871,6 +898,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 7) g_sq_lanes = value;
     else if (key == 8) set_symbolic_tuning(value);
     else if (key == 9) set_fold_first(value);
+    else if (key == 13) g_compact = value;
     else set_spmm_tuning(key, value);
 }
 

@@ -420,3 +420,26 @@ def test_chebyshev_launch_folds_keep_the_preconditioner(precision, mesh3d, gpu_c
     finally:
         L.remo_debug_tune(9, 1)
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_compact_vertex_block_is_the_same_operator(precision, mesh3d, gpu_ctx):
+    """Above 16 k vertices the Chebyshev launches read a compact copy of the vertex block instead of the leading entries of A's
+    rows (remo_debug_tune key 13; 2 forces it on the small test mesh): same entries in the same order, so the same steps and
+    potentials, with the first step inside the update launch (key 9) or on its own."""
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        res = {}
+        for fold in (1, 0):
+            for compact in (0, 2):
+                L.remo_debug_tune(9, fold); L.remo_debug_tune(13, compact)
+                assert b.run(solver.make_opts(rtol=1e-10, precision=precision)) == 0
+                res[(fold, compact)] = (np.concatenate(b.fetch()), b.stats["pcg_steps"])
+            assert res[(fold, 0)][1] == res[(fold, 2)][1], fold
+            assert np.array_equal(res[(fold, 0)][0], res[(fold, 2)][0]), fold
+    finally:
+        L.remo_debug_tune(9, 1); L.remo_debug_tune(13, 1)
+        b.close()

@@ -598,11 +598,14 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
     // default row schedule of the pair kernel: XCD windows (measured 69 -> 60 us at 334k rows, k = 5); once the matrix no
-    // longer stays in the 256 MB of MALL between launches (3D, more than ~20 M stored entries), XCD regions of 4 chunks
-    // each: inside the solver loop (bench.py --tune 3=1 against 3=64 on one box) 152.7 -> 149.8 us at 716k rows,
+    // longer stays in the 256 MB of MALL between launches (3D, more than ~20 M stored entries), XCD regions (4 chunks
+    // each in these measurements): inside the solver loop (bench.py --tune 3=1 against 3=64 on one box) 152.7 -> 149.8 us at 716k rows,
     // 490.8 -> 480.2 us at 2.17 M rows, but 58.6 -> 60.0 us at 289k rows (the stand-alone probe, tools/probe_regions.py,
     // shows 2 ... 16 chunks within 1 % of each other)
-    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : ((lpr == 16 && A.nnz > 20000000) ? 64 : 1);
+    // chunks per XCD: about 0.4 MB of x per chunk, 4 ... 64 (bench at 5.4 M rows: 4 chunks 1257 us, 16: 1227, 64: 1216)
+    int64_t nc = (A.n * int64_t(K) * int64_t(sizeof(T)) / 8 + 210000) / 420000;
+    nc = nc < 4 ? 4 : (nc > 64 ? 64 : nc);
+    const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : ((lpr == 16 && A.nnz > 20000000) ? int(16 * nc) : 1);
 #define REMO_SPMM(L)                                                                                                        \
     if (part)                                                                                                               \
         hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \

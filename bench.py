@@ -9,52 +9,89 @@ with the build's task builder, pinned against the reference's in tests/golden/ta
 Batch meshes are seeded synthetic half-ball meshes with the reference's size field (no Gmsh in
 the image); their sizes (T, n, nnz) are printed in the JSON line.
 
-One "step" = one pass of the hot path over every batch of this rank's share: dof numbering,
-CSR pattern, assembly, multi-RHS two-level PCG, axis evaluation, apparent resistivity — then ONE
-all-reduce of the log slab across ranks (RCCL).  Mesh arrays, sigma and points are resident on
-the device before the timed region (remo_batch_create); mesh generation is excluded, as SURVEY.md
-section 8d defines the point.
+One "step" = one pass of the hot path over every batch of the sweep: dof numbering, CSR pattern,
+assembly, multi-RHS two-level PCG, axis evaluation, apparent resistivity — then ONE all-reduce of
+the log slab across ranks (RCCL).  Mesh arrays, sigma and points are resident on the device before
+the timed region (remo_batch_create); mesh generation is excluded, as SURVEY.md section 8d defines
+the point.  The same line also carries: the rate with the per-batch host->device copy inside the
+timed span (remo_solve_batch, `value_h2d_inclusive`), and the same workload at the larger mesh sizes and on
+the interface-conforming meshes `Model` uses (`sizes`).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torchrun, one rank
-per GPU.  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launched by torchrun (one
+rank per GPU), or started plainly: the parent then spawns the N ranks itself (torch.distributed.run)
+before it has touched torch or the GPU, relays rank 0's JSON line and the children's exit status.
+`--gpus N` never runs on fewer than N ranks.  Rank 0 prints ONE JSON line.
+
+Scaling modes: default weak (`--depths` per GPU, BASELINE configs[2] per GPU); `--total-depths D` = strong
+(BASELINE configs[3]: 1000 depths over the ranks).  `--schedule dynamic`: ranks draw batches from a shared
+counter (the reference's pull scheduling, remo3d.py:843-860) instead of block-cyclic shares.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SIZES = {"S": 4.0, "M": 2.5, "L": 1.2, "XL": 0.7}   # multiplier on the reference size field
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TOOLS = ["A0.4M6.0N", "A2.0M0.5N"]
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic_default_bench.json")
 
 
-def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice"):
-    from remo3d_amd import geometry, tasks
-    from remo3d_amd.model import Model, default_mesh_provider
+def _model_and_batches(n_depths):
+    import numpy as np
+    from remo3d_amd import tasks
+    from remo3d_amd.model import Model
     ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
-    names = ["A0.4M6.0N", "A2.0M0.5N"]
-    m = Model(names)
+    m = Model(TOOLS)
     m.set_model_parameters(os.path.join(ex, "Formation_BM3_30.txt"), os.path.join(ex, "Borehole_BM3.txt"), dip=30)
     m.borehole_model = m._add_points_to_borehole()
-    depths = np.linspace(5.0, 20.0, depths_per_gpu * world, endpoint=False)
+    depths = np.linspace(5.0, 20.0, n_depths, endpoint=False)
     sim, batches = tasks.build_batches(m.tools, m.sec, depths, 5)
     mud = np.interp(sim, m.borehole_model[:, 0], m.borehole_model[:, 2])
     bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    return m, depths, sim, batches, mud, bg
+
+
+def _build_some(job):
+    """Meshes + right-hand sides of the batches `indices` (runs in the caller or in a spawned CPU-only process)."""
+    n_depths, scale, mesh_3d, indices = job
+    from remo3d_amd import geometry, tasks
+    from remo3d_amd.model import default_mesh_provider
+    m, depths, sim, batches, mud, bg = _model_and_batches(n_depths)
     provider = default_mesh_provider(scale=scale, seed=0, mesh_3d=mesh_3d)
-    work = []
-    t0 = time.time()
-    for bi in range(rank, len(batches), world):
+    out = []
+    for bi in indices:
         b = batches[bi]
         fg, bh, sigma = geometry.select_data_range(bg, m.formation_model, m.dip_rad, mud[bi], sim[bi], 50.0)
-        mesh = provider(dim, 50.0, b, fg, bh, m.dip_rad)
+        mesh = provider(3, 50.0, b, fg, bh, m.dip_rad)
         sources, evals, readers = tasks.batch_rhs(b, m.tools)
-        work.append(dict(mesh=mesh, sigma=sigma, sources=sources, evals=evals, readers=readers))
-    return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=names)
+        out.append(dict(index=bi, mesh=mesh, sigma=sigma, sources=sources, evals=evals, readers=readers))
+    return out
+
+
+def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice", total_depths=None, all_batches=False, max_batches=None,
+                   pool=None):
+    """Batches of this rank (block-cyclic share; all of them when all_batches) with meshes and right-hand sides.
+    pool: a concurrent.futures executor of CPU-only processes that build the meshes side by side."""
+    n_depths = int(total_depths) if total_depths else depths_per_gpu * world
+    m, depths, sim, batches, mud, bg = _model_and_batches(n_depths)
+    mine = list(range(len(batches))) if all_batches else list(range(rank, len(batches), world))
+    if max_batches:
+        mine = mine[:max_batches]
+    t0 = time.time()
+    if pool is not None and len(mine) > 1:
+        nw = getattr(pool, "_max_workers", 4)
+        chunks = [mine[i::nw] for i in range(nw) if mine[i::nw]]
+        futs = [pool.submit(_build_some, (n_depths, scale, mesh_3d, c)) for c in chunks]
+        work = sorted((w for f in futs for w in f.result()), key=lambda w: w["index"])
+    else:
+        work = _build_some((n_depths, scale, mesh_3d, mine))
+    return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=list(TOOLS))
 
 
 def cpu_baseline(work, rtol, cores=None):
@@ -102,7 +139,7 @@ def pmc_traffic(workload, n_free, nnz):
     """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this exact workload
     (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic_default_bench.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             p = json.load(f)
     except OSError:
         return None
@@ -111,13 +148,147 @@ def pmc_traffic(workload, n_free, nnz):
     return None
 
 
+def self_launch(args, argv):
+    """--gpus N without a torchrun environment: spawn the N ranks as fresh child processes (this parent has not imported
+    torch nor touched the GPU), relay rank 0's JSON line, exit non-zero if any rank failed."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank launch failed (exit status {r.returncode})\n")
+        raise SystemExit(r.returncode or 1)
+    rec = json.loads(line)
+    if rec.get("n_gpus") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} ranks, the line says {rec.get('n_gpus')}\n")
+        raise SystemExit(1)
+    print(line)
+
+
+class Runner:
+    """The timed part: resident batches of one context set, one pass = one_step()."""
+
+    def __init__(self, work, n_depths, local, opts, streams=1, schedule="static", all_resident=False):
+        import numpy as np
+        from remo3d_amd import solver, sweep, tasks
+        self.np, self.sweep, self.tasks = np, sweep, tasks
+        self.work, self.n_depths, self.opts, self.schedule = work, n_depths, opts, schedule
+        self.ctxs = [solver.Context(local) for _ in range(max(1, streams))]
+        self.resident = [self.ctxs[i % len(self.ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
+        self.all_resident = all_resident          # dynamic schedule: every rank holds every batch, the queue index is the batch index
+        self.pool = None
+        if len(self.ctxs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self.pool = ThreadPoolExecutor(max_workers=len(self.ctxs))
+
+    def close(self):
+        for b in self.resident:
+            b.close()
+        for c in self.ctxs:
+            c.close()
+
+    def _collect(self, i, rc, slab, agg):
+        np = self.np
+        w, b = self.work[i], self.resident[i]
+        st = b.stats
+        if rc < 0:
+            for rd in w["readers"]:
+                for (di, ti, K, o, m) in rd:
+                    slab[di, ti] = np.nan
+            return
+        agg["not_converged"] += int(rc == 1)
+        outs = b.fetch()
+        for u, rd in zip(outs, w["readers"]):
+            for (di, ti, K, o, m) in rd:
+                slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, 3)
+        agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
+        agg["spmv_ms_raw"] += st["spmv_ms_raw"]; agg["ev_over"] = st["event_overhead_ms"]
+        agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
+        agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
+        for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
+            agg[k] += st[k]
+        agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]; agg["batches"] += 1
+
+    def one_step(self, h2d_inclusive=False):
+        np = self.np
+        slab = np.zeros((self.n_depths, len(TOOLS)))
+        agg = dict(spmv_ms=0.0, spmv_ms_raw=0.0, spmv_launches=0, spmv_bytes_total=0.0, pcg_steps=0, not_converged=0, ms_symbolic=0.0,
+                   ms_assemble=0.0, ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0, batches=0, ev_over=0.0)
+        t_busy = time.time()
+        if h2d_inclusive:     # the host-buffer entry: every batch is copied to the device inside the timed span (remo_solve_batch)
+            for w in self.work:
+                outs, st, rc = self.ctxs[0].solve_batch(w["mesh"], w["sigma"], w["sources"], w["evals"], self.opts, raise_on_error=False)
+                for u, rd in zip(outs, w["readers"]):
+                    for (di, ti, K, o, m) in rd:
+                        slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, 3) if rc >= 0 else np.nan
+                agg["ms_h2d"] += st["ms_h2d"]; agg["batches"] += 1
+        elif self.pool is not None:   # one host thread per context, each walks its own batches in order (ctypes releases the GIL)
+            def drive(j):
+                return [(i, self.resident[i].run(self.opts, raise_on_error=False)) for i in range(j, len(self.resident), len(self.ctxs))]
+            for i, rc in sorted(p for chunk in self.pool.map(drive, range(len(self.ctxs))) for p in chunk):
+                self._collect(i, rc, slab, agg)
+        else:
+            queue = self.sweep.BatchQueue(len(self.work), self.schedule) if self.all_resident else range(len(self.work))
+            for i in queue:
+                self._collect(i, self.resident[i].run(self.opts, raise_on_error=False), slab, agg)
+        agg["busy_s"] = time.time() - t_busy
+        slab = self.sweep.combine(slab)   # the ONE collective of the path: all-reduce of the log slab
+        return slab, agg
+
+
+def timed(runner, steps, warmup, sync, **kw):
+    for _ in range(warmup):
+        runner.one_step(**kw)
+    sync()
+    t0 = time.time()
+    busy = 0.0
+    for _ in range(steps):
+        slab, agg = runner.one_step(**kw)
+        busy += agg["busy_s"]
+    sync()
+    return time.time() - t0, slab, agg, busy
+
+
+def roofline_of(agg, precision, stride, workload_name=None):
+    ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
+    r = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
+             traffic=pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"])) if (workload_name and precision == "fp64") else None)
+    r.update(kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if precision == "fp64" else "fp32 values and vectors"),
+             timed="every %d-th launch of every solve, HIP events on the solver's stream, over the timed steps" % stride,
+             launches=int(agg["spmv_launches"]),
+             avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+             avg_bracket_us_raw=(1e3 * agg["spmv_ms_raw"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+             empty_event_pair_us=1e3 * agg["ev_over"],
+             bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)",
+             traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, " + PMC_FILE)
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", default="S", choices=list(SIZES))
-    ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU")
+    ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU (weak scaling)")
+    ap.add_argument("--total-depths", type=int, default=0,
+                    help="strong scaling: this many depths in all, shared by the ranks (BASELINE configs[3]: 1000)")
+    ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
+                    help="static = block-cyclic shares; dynamic = ranks draw batches from a shared counter while they are free "
+                         "(the reference's pull scheduling); every rank then keeps every batch resident")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxsteps", type=int, default=1000)
     ap.add_argument("--mesh", default="lattice", choices=["lattice", "conforming"],
@@ -132,6 +303,11 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sizes", default="M:8,L:4,conforming-M:8",
+                    help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes), "
+                         "reported in the `sizes` array; '' = none")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
+    ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip.h lists the keys)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
@@ -140,12 +316,44 @@ def main():
                          "every launch takes 6 %% off the throughput it is there to explain)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, sys.argv[1:])        # nothing of torch / HIP has been loaded in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # REMO_DEVICE: rehearsals on a 1-GPU box
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    from remo3d_amd import solver, sweep, tasks
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different number of ranks")
+
+    import numpy as np
+    strong = args.total_depths > 0
+    dynamic = args.schedule == "dynamic" and world > 1
+    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune
+    extra_specs = []
+    if extras and args.sizes:
+        for spec in args.sizes.split(","):
+            name, nb = spec.split(":")
+            conf = name.startswith("conforming-")
+            size = name.split("-")[-1]
+            if not (size == args.size and not conf):
+                extra_specs.append((name, size, "conforming" if conf else "lattice", int(nb)))
+
+    # ---- synthetic meshes: CPU-only worker processes, before this process loads the HIP library ----
+    mesh_pool = None
+    if args.mesh_workers > 1 and world == 1:
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        mesh_pool = ProcessPoolExecutor(max_workers=args.mesh_workers, mp_context=multiprocessing.get_context("spawn"))
+    t_mesh0 = time.time()
+    wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh, total_depths=args.total_depths or None,
+                        all_batches=dynamic, pool=mesh_pool)
+    extra_wl = [(name, build_workload(0, 1, 100, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)) for name, size, kind, nb in extra_specs]
+    if mesh_pool is not None:
+        mesh_pool.shutdown()
+    mesh_wall = time.time() - t_mesh0
+
+    from remo3d_amd import solver, sweep
     if args.tune:
         from remo3d_amd import _lib
         for kv in args.tune:
@@ -158,50 +366,13 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
 
-    wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh)
-    work = wl["work"]
-    ctx = solver.Context(local)
+    stride = max(1, args.event_stride)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
-                            time_kernels=0 if args.no_events else max(1, args.event_stride), precision=args.precision,
+                            time_kernels=0 if args.no_events else stride, precision=args.precision,
                             serialize_solves=(args.streams > 1 and args.overlap == "prepare"))
-    ctxs = [ctx] + [solver.Context(local) for _ in range(max(1, args.streams) - 1)]
-    resident = [ctxs[i % len(ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
-    n_tools = len(wl["names"])
-    pool = None
-    if len(ctxs) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=len(ctxs))
-
-    def one_step():
-        slab = np.zeros((len(wl["depths"]), n_tools))
-        agg = dict(spmv_ms=0.0, spmv_launches=0, spmv_bytes_total=0.0, pcg_steps=0, not_converged=0, ms_symbolic=0.0, ms_assemble=0.0,
-                   ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0)
-        if pool is not None:   # one host thread per context, each walks its own batches in order (ctypes releases the GIL)
-            def drive(j):
-                return [(i, resident[i].run(opts, raise_on_error=False)) for i in range(j, len(resident), len(ctxs))]
-            rcs = dict(p for chunk in pool.map(drive, range(len(ctxs))) for p in chunk)
-        for i, (w, b) in enumerate(zip(work, resident)):
-            rc = rcs[i] if pool is not None else b.run(opts, raise_on_error=False)
-            st = b.stats
-            if rc < 0:
-                for rd in w["readers"]:
-                    for (di, ti, K, o, m) in rd:
-                        slab[di, ti] = np.nan
-                continue
-            agg["not_converged"] += int(rc == 1)
-            outs = b.fetch()
-            for u, rd in zip(outs, w["readers"]):
-                for (di, ti, K, o, m) in rd:
-                    slab[di, ti] = tasks.apparent_resistivity(u[o:o + m], m, K, 3)
-            agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
-            agg["spmv_ms_raw"] = agg.get("spmv_ms_raw", 0.0) + st["spmv_ms_raw"]; agg["ev_over"] = st["event_overhead_ms"]
-            agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
-            agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
-            for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
-                agg[k] += st[k]
-            agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]
-        slab = sweep.combine(slab)   # the ONE collective of the path: all-reduce of the log slab
-        return slab, agg
+    work = wl["work"]
+    n_depths = len(wl["depths"])
+    runner = Runner(work, n_depths, local, opts, streams=args.streams, schedule=args.schedule, all_resident=dynamic)
 
     def sync():
         if dist_on:
@@ -210,52 +381,66 @@ def main():
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.time()
-    for _ in range(args.steps):
-        slab, agg = one_step()
-    sync()
-    dt = sweep.max_over_ranks(time.time() - t0)
+    dt_local, slab, agg, busy = timed(runner, args.steps, args.warmup, sync)
+    dt = sweep.max_over_ranks(dt_local)
+    busy_ranks = sweep.gather_floats([1e3 * busy / args.steps, float(agg["batches"])])
 
-    n_points = len(wl["depths"]) * n_tools
+    n_points = n_depths * len(TOOLS)
     value = n_points * args.steps / dt
-    workload_name = f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {args.depths} depths/GPU, R=50, batch 5, mesh size {args.size}"
+    per = f"{args.total_depths} depths in all" if strong else f"{args.depths} depths/GPU"
+    workload_name = f"BM3 dip30, tools A0.4M6.0N+A2.0M0.5N, {per}, R=50, batch 5, mesh size {args.size}"
     if args.mesh != "lattice":
         workload_name += ", interface-conforming revolved meshes"
     if rank != 0:
+        runner.close()
         return
-    ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
-    roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
-                    traffic=pmc_traffic(workload_name,
-                                        int(agg["n"]), int(agg["nnz"])) if args.precision == "fp64" else None,
-                    kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if args.precision == "fp64" else "fp32 values and vectors"),
-                    timed="every %d-th launch of every solve, HIP events on the solver's stream, over the timed steps" % max(1, args.event_stride), launches=int(agg["spmv_launches"]),
-                    avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
-                    avg_bracket_us_raw=(1e3 * agg.get("spmv_ms_raw", 0.0) / agg["spmv_launches"]) if agg["spmv_launches"] else None,
-                    empty_event_pair_us=1e3 * agg.get("ev_over", 0.0),
-                    bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if args.precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)", traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, profiles/r01_f_pmc_traffic_default_bench.json")
     out = dict(metric="measurement points/sec (3D benchmark model)", value=value, unit="points/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f64" if args.precision == "fp64" else "f32 PCG inside f64 residual refinement", data="synthetic",
-               config=dict(workload=workload_name,
-                           batches_per_gpu=len(work), rhs_per_gpu=sum(len(w["sources"]) for w in work), points_total=n_points,
-                           mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=len(ctxs), preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs", max_pcg_iterations=int(agg["max_it"]),
-                           batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
-               roofline=roofline,
-               breakdown_ms_per_step=dict(symbolic_host=agg["ms_symbolic"], h2d=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],
-                                          eval=agg["ms_eval"], pcg_steps=int(agg["pcg_steps"]), mesh_generation_excluded_s=wl["mesh_s"]))
+               warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong" if strong else "weak",
+               vs_baseline=None, dtype="f64" if args.precision == "fp64" else "f32 PCG inside f64 residual refinement", data="synthetic",
+               config=dict(workload=workload_name, schedule=args.schedule if world > 1 else "single rank",
+                           batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
+                           points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams,
+                           preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
+                           max_pcg_iterations=int(agg["max_it"]), batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
+               roofline=roofline_of(agg, args.precision, stride, workload_name),
+               breakdown_ms_per_step=dict(numbering_and_pattern_device=agg["ms_symbolic"], h2d_points=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],
+                                          eval=agg["ms_eval"], pcg_steps=int(agg["pcg_steps"]), mesh_generation_excluded_s=wl["mesh_s"],
+                                          all_mesh_generation_wall_s=mesh_wall),
+               per_rank=dict(busy_ms_per_step=[b[0] for b in busy_ranks], batches_last_step=[int(b[1]) for b in busy_ranks]))
     if args.tune:
         out["config"]["debug_tune"] = list(args.tune)
+
+    if extras:
+        # the same sweep with the per-batch host -> device copy of the mesh arrays INSIDE the timed span (SURVEY 8d's span; the
+        # one-shot entry remo_solve_batch: create + run + fetch + destroy per batch)
+        dth, slab_h, agg_h, _ = timed(runner, max(1, min(args.steps, 2)), 1, sync, h2d_inclusive=True)
+        out["value_h2d_inclusive"] = dict(value=n_points * max(1, min(args.steps, 2)) / dth, unit="points/s",
+                                          note="remo_solve_batch per batch: upload of the mesh arrays (pageable host memory) + run + fetch inside the timed span",
+                                          max_abs_log_diff_vs_resident=float(np.nanmax(np.abs(slab_h - slab))))
     if not args.no_cpu and world == 1:           # the CPU leg belongs to the N = 1 line only
         cb, ref_out = cpu_baseline(work, args.rtol)
         out["cpu_baseline"] = cb
-        got = resident[0].fetch()[0]
+        got = runner.resident[0].fetch()[0]
         out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got - ref_out) / np.abs(ref_out)))
     else:
         out["cpu_baseline"] = None
+    runner.close()
+
+    sizes = []
+    for name, w2 in extra_wl:
+        r2 = Runner(w2["work"], len(w2["depths"]), local, opts)
+        st2 = 2
+        dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
+        pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
+        rf = roofline_of(agg2, args.precision, stride)
+        sizes.append(dict(workload=name, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
+                          n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
+                          max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"], spmm_avg_launch_us=rf["avg_launch_us"],
+                          solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))
+        r2.close()
+    if extras:
+        out["sizes"] = sizes
     print(json.dumps(out))
 
 

@@ -154,6 +154,11 @@ int remo_batch_eval(remo_ctx_t *ctx, remo_batch_t *batch, int32_t rhs, int32_t n
  */
 int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *batch, int32_t *rowptr, int32_t *col,
                           double *val, double *dinv, int32_t *freeid);
+/* Solution and load vectors of the LAST chunk of right-hand sides of the last remo_batch_run (chunks hold at most
+ * REMO_MAX_RHS columns): x[n_free * k], f[n_free * k], row-major with k = *k_out columns.  Either pointer may be NULL.
+ * With remo_batch_spmv this lets a test measure the TRUE residual f - A x of what CGSolver's silent stopping rule
+ * (ngsolve_functions.py:50-51) left behind. */
+int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *batch, double *x, double *f, int32_t *k_out);
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */
 int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *x, double *y,

@@ -51,7 +51,7 @@ template <class T> struct CsrViewT {
     int64_t nnz;
     const int32_t *rowptr;
     const int32_t *col;
-    const T *val;
+    const T *val;          // [nnz + 1] allocated: the pair SpMM loads two values per stored entry, so the last entry of a single row reads one element past nnz
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
     // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
@@ -72,7 +72,8 @@ void set_fold_first(int v);                 // 1 (default): FIRST Chebyshev step
 void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 threads, 3 mapping, 4 grid (0 = default)
 int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
-template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s);
+// scal != nullptr: the launch belongs to PCG step `step` and returns at once when an earlier step froze every column
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step = 0);
 
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)

@@ -181,10 +181,16 @@ __device__ __forceinline__ int64_t value_pos(int64_t row, int32_t rs, int32_t le
     return int64_t(second ? rs - len : rs) + 2 * int64_t(e) + (second ? 1 : 0);
 }
 
-// scal[kDoneSlot] (as int) is raised by the update launch once every column is frozen; the remaining
-// launches the host has already queued (it runs a few steps ahead of the device) then return at once.
+// scal[kDoneSlot] (as int) is set to s + 1 by the update launch of step s once every column is frozen; the launches of
+// LATER steps that the host has already queued (it runs a few steps ahead of the device) then return at once.  The
+// launches of step s itself (the update that raises the flag included) never act on it: a workgroup whose waves start
+// on both sides of the store would otherwise split, the early leavers missing from the block sums of the rest.  They
+// run a harmless step instead (alpha = beta = 0 for every column).
 constexpr int kDoneSlot = 4 * 8;
-__device__ __forceinline__ bool solve_done(const double *scal) { return reinterpret_cast<const int *>(scal + kDoneSlot)[0] != 0; }
+__device__ __forceinline__ bool solve_done(const double *scal, int step) {
+    const int d = reinterpret_cast<const int *>(scal + kDoneSlot)[0];
+    return d != 0 && d <= step;
+}
 
 // ------------------------------------------------------------------------------------------
 // metric terms: one thread per element (ngsolve_functions.py:33-36: the coefficient part of the
@@ -324,8 +330,8 @@ void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, 
 template <class T, int K, int LPR, bool DOT>
 __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                               const int32_t *__restrict__ col, const T *__restrict__ val,
-                                              const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
-    if (scal && solve_done(scal)) return;
+                                              const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int grp = threadIdx.x / LPR;
@@ -374,8 +380,8 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t pair_begin, int
 template <class T, int K, int LPR, bool DOT, int MODE = 0>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
 __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, int xcd_windows, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                   const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal) {
-    if (scal && solve_done(scal)) return;
+                                                   const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
     constexpr int U = 2;
     constexpr int MFP = treduce_out(2 * K, LPR), MFS = treduce_out(K, LPR);   // sums per lane after the reduction
     const int rpb = blockDim.x / LPR;
@@ -471,7 +477,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
                 if (p < re) {                        // lanes past the row end issue nothing (exec-masked loads)
                     j[u] = col[p];
                     // one 16-byte (fp32: 8-byte) load either way: the interleaved values of the two rows of a pair, or a
-                    // single row's value plus its unused right neighbour (always inside the arena: other buffers follow val)
+                    // single row's value plus its unused right neighbour (val is allocated with one element of slack, CsrViewT)
                     typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
                     const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + (pair ? 2 * (p - rs) : (p - rs)));
                     v0[u] = vv.x; v1[u] = vv.y;
@@ -592,7 +598,7 @@ int spmv_grid(int64_t n, int lpr) {
     return int(g);
 }
 
-template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s) {
+template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
     int variant = g_tune.variant ? g_tune.variant : 3;
@@ -608,19 +614,19 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     const int mapping = (g_tune.mapping >= 0) ? g_tune.mapping : ((lpr == 16 && A.nnz > 20000000) ? int(16 * nc) : 1);
 #define REMO_SPMM(L)                                                                                                        \
     if (part)                                                                                                               \
-        hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal); \
+        hipLaunchKernelGGL((k_spmm<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal, step); \
     else                                                                                                                    \
-        hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal)
+        hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal, step)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal); \
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal)
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step)
     if constexpr (K == 5 && sizeof(T) == 8) {   // ablation modes of tools/probe_ablate.py
         if (variant == 3 && lpr == 16 && g_tune.mode >= 1 && g_tune.mode <= 3 && !part) {
-            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
-            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
-            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal);
+            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
             return;
         }
     }
@@ -639,20 +645,20 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 #undef REMO_SPMM_PAIR
 }
 
-template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s) {
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
     switch (k) {
-        case 1: spmm_dispatch<T, 1>(A, x, y, part, scal, nb, s); break;
-        case 2: spmm_dispatch<T, 2>(A, x, y, part, scal, nb, s); break;
-        case 3: spmm_dispatch<T, 3>(A, x, y, part, scal, nb, s); break;
-        case 4: spmm_dispatch<T, 4>(A, x, y, part, scal, nb, s); break;
-        case 5: spmm_dispatch<T, 5>(A, x, y, part, scal, nb, s); break;
-        case 6: spmm_dispatch<T, 6>(A, x, y, part, scal, nb, s); break;
-        case 7: spmm_dispatch<T, 7>(A, x, y, part, scal, nb, s); break;
-        default: spmm_dispatch<T, 8>(A, x, y, part, scal, nb, s); break;
+        case 1: spmm_dispatch<T, 1>(A, x, y, part, scal, step, nb, s); break;
+        case 2: spmm_dispatch<T, 2>(A, x, y, part, scal, step, nb, s); break;
+        case 3: spmm_dispatch<T, 3>(A, x, y, part, scal, step, nb, s); break;
+        case 4: spmm_dispatch<T, 4>(A, x, y, part, scal, step, nb, s); break;
+        case 5: spmm_dispatch<T, 5>(A, x, y, part, scal, step, nb, s); break;
+        case 6: spmm_dispatch<T, 6>(A, x, y, part, scal, step, nb, s); break;
+        case 7: spmm_dispatch<T, 7>(A, x, y, part, scal, step, nb, s); break;
+        default: spmm_dispatch<T, 8>(A, x, y, part, scal, step, nb, s); break;
     }
 }
-template void launch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t);
-template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t);
+template void launch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int);
+template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int);
 
 // ------------------------------------------------------------------------------------------
 // Jacobi-PCG vector kernels (CGSolver(a.mat, c.mat), ngsolve_functions.py:50-51), K columns at
@@ -730,7 +736,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
     double *scal = rz0;
-    if (solve_done(scal)) return;
+    if (solve_done(scal, step)) return;
     double pq[K], rz[K], unused[K], alpha[K], acc[K];
     if (step == 0) {
         reduce_partials3<K>(part_pq, nb_spmv, part_rz_cur, nb_rz, nullptr, 0, pq, rz, unused, smem);
@@ -751,7 +757,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
         for (int c = 0; c < K; ++c) any_live |= (alpha[c] != 0.0);
         if (!any_live) {   // every column frozen: later launches of this solve are no-ops; tell the host where it ended
-            reinterpret_cast<int *>(scal + kDoneSlot)[0] = 1;
+            reinterpret_cast<int *>(scal + kDoneSlot)[0] = step + 1;   // acts on the launches of steps > step only (solve_done)
             publish_progress(progress + (progress_len - 1), rz, K, step);
         }
 #pragma unroll
@@ -851,11 +857,11 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
                                                    const T *__restrict__ val, const T *__restrict__ dinv,
                                                    const T *__restrict__ d_old, T *__restrict__ d_new,
                                                    T *__restrict__ z, T *__restrict__ res, double c1_, double c2_, double inv_theta_,
-                                                   T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit) {
+                                                   T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit, int step) {
     const T c1 = T(c1_), c2 = T(c2_), inv_theta = T(inv_theta_);
     constexpr int LPR = 8, RPB = 256 / LPR;
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
-    if (solve_done(scal)) return;
+    if (solve_done(scal, step)) return;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     // the kernel is a chain of dependent round trips on a tiny block (launch-latency class): after the
     // transposing reduction lane `sub` owns column mycol of its row, so the vectors of the update are
@@ -923,7 +929,7 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
                                                        const T *__restrict__ r, T *__restrict__ p,
                                                        const T *__restrict__ dinv) {
     __shared__ double smem[16 * K];
-    if (solve_done(scal)) return;
+    if (solve_done(scal, step)) return;
     double beta[K];
     if (first) {  // p0 = C r0
 #pragma unroll
@@ -980,7 +986,7 @@ template <int K>
 __global__ void __launch_bounds__(256) k_pcg_final(int step, int nb_rz, const double *__restrict__ part_rz, const double *__restrict__ scal,
                                                    PcgProgress *progress, int progress_len) {
     __shared__ double smem[16 * K];
-    if (solve_done(scal)) return;   // the "done" record already holds the final <Cr,r>
+    if (solve_done(scal, step)) return;   // the "done" record already holds the final <Cr,r>
     double rz[K];
     reduce_partials<K>(part_rz, nb_rz, rz, smem);
     if (threadIdx.x == 0) publish_progress(progress + (step % (progress_len - 1)), rz, K, step);
@@ -1183,10 +1189,10 @@ template <class T, int K, int LPR, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const T *__restrict__ va, const T *__restrict__ vb, const T *__restrict__ dinv,
                                                    const T *__restrict__ w_old, T *__restrict__ w_new, T *__restrict__ z, double ab_sum_, double ab_prod_,
-                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal) {
+                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int step) {
     constexpr int RPB = 256 / LPR, U = 2;
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
-    if (solve_done(scal)) return;
+    if (solve_done(scal, step)) return;
     const T ab_sum = T(ab_sum_), ab_prod = T(ab_prod_);
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     int idx[K], own[K];
@@ -1296,7 +1302,7 @@ template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b) {
     return g_fold_first && b.cheb_degree >= 3 && b.nv_coarse > 0 && b.nv_coarse <= 32768 && !(b.sq_rowptr && (b.cheb_degree & 1) == 0);
 }
 
-template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s, bool first_done = false) {
+template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s, bool first_done = false) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
     if (b.sq_rowptr && (b.cheb_degree & 1) == 0) {   // two Richardson factors of the Chebyshev polynomial per launch
         const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
@@ -1316,7 +1322,7 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
             auto grid_for = [&](int lpr) { int64_t gg = (b.nv_coarse + 256 / lpr - 1) / (256 / lpr); if (last && gg > g_last) gg = g_last; if (gg > 4096) gg = 4096; return int(gg); };
 #define REMO_CHEB2(LPRV, F, L)                                                                                                                        \
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_pair<T, KK, LPRV, F, L>), dim3(grid_for(LPRV)), dim3(256), 0, s, b.nv_coarse, b.sq_rowptr, b.sq_col, b.sq_a, \
-                                        b.sq_b, b.dinv, wold, wnew, b.cz, a + bb, a * bb, b.r, part, b.rz0))
+                                        b.sq_b, b.dinv, wold, wnew, b.cz, a + bb, a * bb, b.r, part, b.rz0, step))
 #define REMO_CHEB2_FL(LPRV)                                 \
     if (first && last) { REMO_CHEB2(LPRV, true, true); }    \
     else if (first) { REMO_CHEB2(LPRV, true, false); }      \
@@ -1354,7 +1360,7 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, const Pc
         const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
 #define REMO_CHEB(F, L)                                                                                                                             \
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, vval, b.dinv, dold, dnew, \
-                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit))
+                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit, step))
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
         else if (last) { REMO_CHEB(false, 2); }
@@ -1370,7 +1376,7 @@ template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f,
     const int g = b.nb_vec;
     const ChebArgsT<T> ch = cheb_args(b);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_init<T, KK>), dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
-    launch_cheb(A, k, b, b.part_rz, s);
+    launch_cheb(A, k, 0, b, b.part_rz, s);
     if (ch.nv > 0)
         REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv));
 }
@@ -1395,7 +1401,7 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     }
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold));
-    launch_cheb(A, k, b, nxt, s, folded);
+    launch_cheb(A, k, step, b, nxt, s, folded);
 }
 
 // Residual replacement of the mixed mode, in place of launch_pcg_update at the chosen steps:
@@ -1405,9 +1411,9 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
 template <int K>
 __global__ void __launch_bounds__(256) k_mixed_replace(int64_t n, int64_t nv, const double *__restrict__ f, const double *__restrict__ q64,
                                                        float *__restrict__ r, const float *__restrict__ dinv, double *__restrict__ part_rz_next,
-                                                       const double *__restrict__ scal) {
+                                                       const double *__restrict__ scal, int step) {
     __shared__ double smem[16 * K];
-    if (solve_done(scal)) return;
+    if (solve_done(scal, step)) return;
     double acc[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) acc[c] = 0.0;
@@ -1435,9 +1441,9 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>()));
     launch_mixed_accumulate(n * k, x64, b.x, 1, s);
-    launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0));
-    launch_cheb(A, k, b, nxt, s);
+    launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s, 0);
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0, step));
+    launch_cheb(A, k, step, b, nxt, s);
 }
 
 template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {

@@ -106,6 +106,7 @@ struct remo_batch {
     CsrView A{};
     double *d_val = nullptr, *d_dinv = nullptr;
     double *d_x = nullptr, *d_C = nullptr;  // solution block [n][k_last] and metric terms of the last run
+    double *d_f = nullptr;                  // load vectors [n][k_last] of the last chunk
     int k_last = 0;
     uint64_t run_id = 0;
     std::vector<double> u_out;
@@ -168,11 +169,11 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
         // time_kernels = k: every k-th SpMM launch is bracketed with events (a bracket costs the stream ~1.5 us)
         if (time_kernels > 0 && (step % time_kernels) == (time_kernels / 2) && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
-            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
             ev_used += 2;
         } else {
-            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
         }
         bool replaced = false;
         if constexpr (std::is_same<T, float>::value) {
@@ -521,7 +522,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t n = sy.nfree;
 
         double *d_C = ctx->take<double>(nt * NT);
-        double *d_val = ctx->take<double>(sy.nnz);
+        double *d_val = ctx->take<double>(sy.nnz + 2);   // + 16 bytes: the SpMM reads single rows' values as 16-byte pairs (CsrViewT)
         double *d_dinv = ctx->take<double>(n);
         double *d_f = ctx->take<double>(n * kmax);
         PcgBuffers buf{};
@@ -650,6 +651,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;
+        b->d_f = d_f;
         b->d_C = d_C;
         b->k_last = 0;
         b->has_system = true;
@@ -664,7 +666,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const bool mixed = (o.precision == 1);
         MixedBuffers mx;
         if (mixed) {   // fp32 images of the system for the inner solver
-            float *v32 = ctx->take<float>(size_t(sy.nnz));
+            float *v32 = ctx->take<float>(size_t(sy.nnz) + 2);   // same slack as d_val
             float *dinv32 = ctx->take<float>(size_t(n));
             launch_to_float(sy.nnz, d_val, v32, s);
             launch_to_float(n, d_dinv, dinv32, s);
@@ -857,6 +859,21 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int
             }
         }
         if (dinv) HIP_TRY(hipMemcpy(dinv, b->d_dinv, sizeof(double) * sy.nfree, hipMemcpyDeviceToHost));
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *b, double *x, double *f, int32_t *k_out) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || !b->has_system || b->run_id != ctx->run_id || b->k_last <= 0) return fail(ctx, REMO_ERR_ARG, "no resident solution on this batch (run it first)");
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const size_t bytes = sizeof(double) * size_t(b->A.n) * size_t(b->k_last);
+        if (x) HIP_TRY(hipMemcpy(x, b->d_x, bytes, hipMemcpyDeviceToHost));
+        if (f) HIP_TRY(hipMemcpy(f, b->d_f, bytes, hipMemcpyDeviceToHost));
+        if (k_out) *k_out = b->k_last;
         return REMO_OK;
     } catch (const std::exception &ex) {
         return fail(ctx, REMO_ERR_DEVICE, ex.what());

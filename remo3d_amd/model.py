@@ -212,13 +212,14 @@ class Model:
         return bm
 
     # -- workers (remo3d.py:552-599, 887-899) ------------------------------------------------------
-    def initialize_workers(self, cpu_workers=4, gpu_workers=0):
+    def initialize_workers(self, cpu_workers=4, gpu_workers=0, context_factory: Optional[Callable] = None):
         """The reference spawns MPI workers here (remo3d.py:552-599); this build opens GPU contexts in the
         calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (at least one), each
         with its own HIP stream and arena and driven by its own host thread in simulate_logs, so batches
         overlap on the GPU the way the reference's GPU workers overlap (two fill the launch-latency gaps of
         one: +15 % in 3D, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
-        cpu_workers is validated like the reference and otherwise unused (there is no CPU solver)."""
+        cpu_workers is validated like the reference and sizes the pool of mesh-generating processes (there is no CPU
+        solver).  Under torchrun this is also where the rank joins the process group (sweep.init_from_env)."""
         if type(cpu_workers) != int or type(gpu_workers) != int:
             raise ValueError("The number of processes have to be an intager")
         if cpu_workers < 1:
@@ -226,10 +227,15 @@ class Model:
         if gpu_workers < 0:
             raise ValueError("Minimal number of gpu workers is 0")
         self.cpu_workers, self.gpu_workers = cpu_workers, gpu_workers
-        from . import solver
-        device = int(os.environ.get("LOCAL_RANK", "0"))
-        self.ctx = solver.Context(device)
-        self.extra_ctx = [solver.Context(device) for _ in range(max(0, min(gpu_workers, 4) - 1))]
+        from . import solver, sweep
+        # under torchrun (WORLD_SIZE > 1) the ranks share the sweep: join the process group here, as the reference
+        # brings its farm up in initialize_workers (remo3d.py:592-599); without it every rank would compute every batch
+        sweep.init_from_env()
+        self.world_size = sweep.world_size()
+        device = int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        make = context_factory or solver.Context     # context_factory(device): a stand-in solver for the CPU tests of the sweep
+        self.ctx = make(device)
+        self.extra_ctx = [make(device) for _ in range(max(0, min(gpu_workers, 4) - 1))]
 
     def shutdown_workers(self):
         for c in getattr(self, "extra_ctx", []):
@@ -246,7 +252,8 @@ class Model:
     # -- the sweep (remo3d.py:723-884 + workers/worker.py:74-142) ----------------------------------
     def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
                       condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: float = 1.0, rtol: float = 1e-8,
-                      maxsteps: int = 1000, verbose: bool = True, mesh_workers: Optional[int] = None, precision: str = "fp64"):
+                      maxsteps: int = 1000, verbose: bool = True, mesh_workers: Optional[int] = None, precision: str = "fp64",
+                      schedule: str = "static"):
         from . import solver, sweep
         start = time.time()
         measurement_depths = np.asarray(measurement_depths, dtype=float)
@@ -294,13 +301,19 @@ class Model:
             return geometry.select_data_range(borehole_geometry, self.formation_model, self.dip_rad if is3d else 0, mud[bi],
                                               simulation_depths[bi], domain_radius)
 
+        # Which batches this rank takes: its block-cyclic share ("static"), or whatever it draws from the shared counter
+        # while it is free ("dynamic", the reference's pull scheduling, remo3d.py:843-860) - sweep.BatchQueue.
         # mesh_workers > 0: the default mesher runs ahead of the solver in that many spawned processes (the
         # reference meshes inside its MPI workers, i.e. in parallel too: worker.py:84-97)
-        mine = list(sweep.my_share(len(batches)))
+        import collections
+        import queue
+        import threading
+        bq = sweep.BatchQueue(len(batches), schedule)
+        share_len = len(list(sweep.my_share(len(batches))))
         pool, pending = None, {}
         if mesh_workers is None:    # default: the reference's cpu_workers mesh (and solve) in parallel; here they mesh, for sweeps long
-            mesh_workers = min(int(self.cpu_workers or 0), 8) if (mesh_provider is None and len(mine) >= 16) else 0   # enough to pay for the start-up
-        if mesh_workers > 0 and mesh_provider is None and len(mine) > 1:
+            mesh_workers = min(int(self.cpu_workers or 0), 8) if (mesh_provider is None and share_len >= 16) else 0   # enough to pay for the start-up
+        if mesh_workers > 0 and mesh_provider is None and share_len > 1:
             import sys
             main_mod = sys.modules.get("__main__")
             hidden = {}
@@ -316,25 +329,41 @@ class Model:
                         setattr(main_mod, attr, None)
                 pool = ProcessPoolExecutor(max_workers=int(mesh_workers), mp_context=multiprocessing.get_context("spawn"),
                                            initializer=_mesh_worker_init, initargs=(dict(scale=mesh_scale),))
-                for bi in mine:      # worker processes are started by these submits
-                    try:
-                        fg, bh, _ = window(bi)
-                        pending[bi] = pool.submit(_mesh_worker_run, (dim, domain_radius, batches[bi].electrodes, fg, bh, self.dip_rad))
-                    except Exception:
-                        pass      # reported when the batch's turn comes
+                # the executor starts a process per submit while none is idle: start them ALL here, while __main__ is hidden
+                for fut in [pool.submit(time.sleep, 0.25) for _ in range(int(mesh_workers))]:
+                    fut.result()
             except Exception:     # no worker processes here: mesh inline
                 pool, pending = None, {}
             finally:
                 for attr, v in hidden.items():
                     setattr(main_mod, attr, v)
-        import queue
-        import threading
         ctxs = [self.ctx] + list(getattr(self, "extra_ctx", []))
         free_ctx = queue.Queue()
         for c in ctxs:
             free_ctx.put(c)
-        acc = dict(mesh=0.0, solve=0.0, points=0)
+        acc = dict(mesh=0.0, solve=0.0, points=0, failed_batches=0, not_converged=0, first_error=None, pcg_steps=0)
         lock = threading.Lock()
+        # batches drawn ahead of the solver so that their meshes are in the making: the whole share at once when it is
+        # fixed anyway, a few (they are OWNED once drawn) under the pull schedule
+        ahead = collections.deque()
+        depth = 1 if pool is None else (share_len if schedule == "static" else int(mesh_workers) + len(ctxs))
+        draw, draw_lock = iter(bq), threading.Lock()
+
+        def next_batch():
+            with draw_lock:
+                while len(ahead) < depth:
+                    try:
+                        bi = next(draw)
+                    except StopIteration:
+                        break
+                    if pool is not None:
+                        try:
+                            fg, bh, _ = window(bi)
+                            pending[bi] = pool.submit(_mesh_worker_run, (dim, domain_radius, batches[bi].electrodes, fg, bh, self.dip_rad))
+                        except Exception:
+                            pass      # reported when the batch's turn comes
+                    ahead.append(bi)
+                return ahead.popleft() if ahead else None
 
         def run_batch(bi):
             batch = batches[bi]
@@ -374,23 +403,47 @@ class Model:
                         n += 1
                 with lock:
                     acc["mesh"] += t1 - t0; acc["solve"] += t2 - t1; acc["points"] += n
-            except Exception:
+                    acc["not_converged"] += int(rc == solver.REMO_NOT_CONVERGED); acc["pcg_steps"] += int(st.get("pcg_steps", 0))
+            except (TypeError, AttributeError, NameError):
+                raise                    # programming errors (e.g. in a custom mesh_provider) are not batch failures
+            except Exception as ex:
                 for di, ti in rows:      # any failure in a batch -> NaN for its records (worker.py:135-138)
                     results[di, ti] = np.nan
+                with lock:               # ... but not silently: the reference's worker at least shows it on stderr
+                    acc["failed_batches"] += 1
+                    if acc["first_error"] is None:
+                        acc["first_error"] = "batch {}: {}: {}".format(bi, type(ex).__name__, ex)
 
-        if len(ctxs) > 1 and len(mine) > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=len(ctxs)) as tp:     # ctypes calls release the GIL
-                list(tp.map(run_batch, mine))
-        else:
-            for bi in mine:
+        def drive():
+            while True:
+                bi = next_batch()
+                if bi is None:
+                    return
                 run_batch(bi)
+
+        t_busy = time.time()
+        if len(ctxs) > 1 and share_len > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(ctxs)) as tp:     # one host thread per context; ctypes calls release the GIL
+                for fut in [tp.submit(drive) for _ in ctxs]:
+                    fut.result()
+        else:
+            drive()
+        t_busy = time.time() - t_busy
+        mine = list(bq.taken)
         t_mesh, t_solve, n_points = acc["mesh"], acc["solve"], acc["points"]
         if pool is not None:
             pool.shutdown(wait=False, cancel_futures=True)
         results = sweep.combine(results)
         self.logs = {name: np.vstack([measurement_depths, results[:, i]]).T for i, name in enumerate(self.tools.keys())}
-        self.timing = dict(total_s=time.time() - start, mesh_s=t_mesh, solve_s=t_solve, points=n_points, batches=len(batches))
+        self.timing = dict(total_s=time.time() - start, mesh_s=t_mesh, solve_s=t_solve, points=n_points, batches=len(batches),
+                           my_batches=len(mine), world_size=sweep.world_size(), schedule=schedule, busy_s=t_busy,
+                           busy_s_per_rank=[b[0] for b in sweep.gather_floats([t_busy])], failed_batches=acc["failed_batches"],
+                           not_converged=acc["not_converged"], first_error=acc["first_error"], pcg_steps=acc["pcg_steps"])
+        if verbose and acc["failed_batches"]:
+            print("rank {}: {} of {} batches failed (NaN in the logs); first: {}".format(sweep.rank(), acc["failed_batches"], len(mine), acc["first_error"]))
+        if verbose and acc["not_converged"]:
+            print("rank {}: PCG stopped at maxsteps in {} batches".format(sweep.rank(), acc["not_converged"]))
         if verbose and sweep.rank() == 0:
             print("\nProcessed in: ", datetime.timedelta(seconds=self.timing["total_s"]))
 

@@ -175,6 +175,37 @@ class Batch:
             raise RemoError(rc, self.ctx.last_error())
         return rowptr, col, val, dinv, freeid
 
+    def jacobi(self):
+        """1 / diag(A) of the last run (remo_batch_get_system, the other arrays skipped)."""
+        n = int(self.stats["n_free"])
+        dinv = np.zeros(n)
+        rc = self._L.remo_batch_get_system(self.ctx._h, self._h, None, None, None, ptr(dinv, C.c_double), None)
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        return dinv
+
+    def vectors(self):
+        """(x, f) of the last chunk of right-hand sides of the last run, each [n_free, k] (remo_batch_get_vectors)."""
+        n = int(self.stats["n_free"])
+        k = C.c_int32(0)
+        rc = self._L.remo_batch_get_vectors(self.ctx._h, self._h, None, None, C.byref(k))
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        x = np.zeros((n, k.value)); f = np.zeros((n, k.value))
+        rc = self._L.remo_batch_get_vectors(self.ctx._h, self._h, ptr(x, C.c_double), ptr(f, C.c_double), C.byref(k))
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        return x, f
+
+    def true_relres(self):
+        """sqrt(<C r, r> / <C f, f>) per column with r = f - A x recomputed from the solution (one device SpMM), C = Jacobi:
+        what the recurrence residual of the PCG claims, measured."""
+        x, f = self.vectors()
+        y, _ = self.spmv(x if x.shape[1] > 1 else x[:, 0])
+        r = f - y.reshape(f.shape)
+        d = self.jacobi()[:, None]
+        return np.sqrt((d * r * r).sum(0) / np.maximum((d * f * f).sum(0), 1e-300))
+
     def spmv(self, x, reps=1):
         """y = A x on the GPU (x: [n] or [n, k]); returns (y, average ms per launch)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -42,6 +42,63 @@ def my_share(n_batches: int, r: Optional[int] = None, w: Optional[int] = None) -
     return range(r, n_batches, w)
 
 
+_QUEUE_SEQ = 0
+
+
+class BatchQueue:
+    """Iterator over the batch indices this rank should take.
+
+    schedule "static": the block-cyclic share (my_share).  schedule "dynamic": the reference's pull scheduling
+    (remo3d.py:843-860: a worker asks the master for the next task index whenever it is free) - here every free rank
+    draws the next index from ONE shared counter, an atomic fetch-add on the process group's rendezvous store (the
+    TCPStore torchrun already runs on the node: a pull is one local round trip, ~0.1 ms against ~20 ms of a 3D batch).
+    Without a process group both schedules are range(n).  Every rank must construct its queues in the same order (the
+    counter's key is a per-process sequence number)."""
+
+    def __init__(self, n_batches: int, schedule: str = "static"):
+        global _QUEUE_SEQ
+        if schedule not in ("static", "dynamic"):
+            raise ValueError("schedule must be 'static' or 'dynamic'")
+        self.n = int(n_batches)
+        self.schedule = schedule
+        self.taken = []
+        _QUEUE_SEQ += 1
+        self._key = "remo3d_batch_queue_%d" % _QUEUE_SEQ
+        self._store = None
+        d = _dist()
+        if schedule == "dynamic" and d is not None and d.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self._store = distributed_c10d._get_default_store()
+
+    def __iter__(self):
+        if self._store is None:
+            for i in (my_share(self.n) if self.schedule == "static" else range(rank(), self.n, world_size())):
+                self.taken.append(i)
+                yield i
+            return
+        while True:
+            i = int(self._store.add(self._key, 1)) - 1      # fetch-add: every index is handed out exactly once
+            if i >= self.n:
+                return
+            self.taken.append(i)
+            yield i
+
+
+def gather_floats(x) -> list:
+    """One small float vector per rank -> list over ranks (per-rank busy times: how balanced was the sweep)."""
+    d = _dist()
+    x = [float(v) for v in np.atleast_1d(x)]
+    if d is None or d.get_world_size() == 1:
+        return [x]
+    import torch
+    t = torch.tensor(x, dtype=torch.float64)
+    if d.get_backend() == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(d.get_world_size())]
+    d.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
+
+
 def init_from_env(backend: Optional[str] = None) -> bool:
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*).
     backend: "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".  Returns True if a

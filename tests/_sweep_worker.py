@@ -38,23 +38,33 @@ class FakeContext:
 
 def main():
     out_path = sys.argv[1]
-    sweep.init_from_env("gloo")
+    schedule = sys.argv[2] if len(sys.argv) > 2 else "static"
+    # no explicit sweep.init_from_env(): Model.initialize_workers joins the process group (REMO_DIST_BACKEND=gloo in the env)
     tools = ["A0.4M6.0N", "A2.0M0.5N", "N0.5M2.0A"]
     m = Model(tools)
     form = np.array([[0.0, 30.0, np.nan, np.nan, 7.0], [30.0, 60.0, np.nan, np.nan, 7.0]])
     bore = np.array([[0.0, 0.2, 7.0], [60.0, 0.2, 7.0]])
     m.set_model_parameters(form, bore)
-    m.ctx = FakeContext()
+    m.initialize_workers(cpu_workers=1, gpu_workers=0, context_factory=lambda device: FakeContext())
     depths = np.arange(10.0, 20.0, 0.25)
     fail_index = 3
 
     def provider(dim, R, batch, fg, bh, dip):
         return "fail" if batch.index == fail_index else "ok"
 
-    m.simulate_logs(depths, domain_radius=50, batch_size=4, mesh_provider=provider, verbose=False)
+    if schedule == "dynamic" and sweep.rank() == 0:      # a slow rank: under the pull schedule the other one takes more batches
+        slow = m.ctx.solve_batch
+
+        def slow_solve(*a):
+            import time
+            time.sleep(0.05)
+            return slow(*a)
+        m.ctx.solve_batch = slow_solve
+    m.simulate_logs(depths, domain_radius=50, batch_size=4, mesh_provider=provider, verbose=False, schedule=schedule)
     n_batches = m.timing["batches"]
-    mine = list(sweep.my_share(n_batches))
-    res = dict(rank=sweep.rank(), world=sweep.world_size(), share=mine, calls=m.ctx.calls,
+    mine = list(sweep.my_share(n_batches)) if schedule == "static" else None
+    res = dict(rank=sweep.rank(), world=sweep.world_size(), share=mine, calls=m.ctx.calls, n_batches=n_batches,
+               taken=m.timing["my_batches"], timing={k: v for k, v in m.timing.items() if k != "first_error"}, first_error=m.timing["first_error"],
                logs={k: v.tolist() for k, v in m.logs.items()})
     with open(f"{out_path}.{sweep.rank()}", "w") as f:
         json.dump(res, f)

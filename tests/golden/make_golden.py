@@ -87,6 +87,7 @@ dump("tasks_bm3.json", tasks_case(tool_sets["bm3"], np.linspace(5, 20, 100, endp
 dump("tasks_bm1_single.json", tasks_case(["A0.4M6.0N"], np.linspace(5, 55, 100), 5))
 dump("tasks_nonsec.json", tasks_case(["B5.7A0.4M", "A2.0M0.5N"], np.arange(2.0, 8.0, 0.2), 4, force=False))
 dump("tasks_example_02.json", tasks_case(tool_sets["example_01"], np.arange(0, 25.1, 0.1), 10))
+dump("tasks_thin_bedded.json", tasks_case(tool_sets["thin_bedded"], np.arange(0, 20.01, 0.25), 5))
 
 
 # ---- model loading + windowing ------------------------------------------------------------------
@@ -147,3 +148,7 @@ dump("netgen_windows_bm2.json", netgen_window_case(os.path.join(bm, "Benchmark m
                                                    np.array([4.8, 15.0, 30.1, 55.0]), 50.0, tool_sets["bm3"]))
 dump("netgen_windows_bm2_r8.json", netgen_window_case(os.path.join(bm, "Benchmark model 2/Formation_BM2.txt"), os.path.join(bm, "Benchmark model 2/Borehole_BM2.txt"),
                                                       np.array([4.8, 15.0, 30.1, 55.0]), 8.0, tool_sets["bm3"]))
+tb = os.path.join(bm, "Thin-bedded model")
+# the formation model ends 2.6 m beyond the first / last measurement depth: the windows of the long tools reach past it
+dump("netgen_windows_thin_bedded.json", netgen_window_case(os.path.join(tb, "Formation/Formation_model_1.txt"), os.path.join(tb, "Borehole/Borehole_model_correct_rm.txt"),
+                                                           np.array([-4.25, 0.0, 2.5, 10.0, 19.5, 24.0]), 50.0, tool_sets["thin_bedded"]))

@@ -45,7 +45,7 @@ def test_bad_tool_names_rejected_like_reference():
 
 
 @pytest.mark.parametrize("fixture", ["tasks_example_01.json", "tasks_bm3.json", "tasks_bm1_single.json", "tasks_nonsec.json",
-                                     "tasks_example_02.json"])
+                                     "tasks_example_02.json", "tasks_thin_bedded.json"])
 def test_batching_matches_reference(fixture):
     gold = load(fixture)
     tables, sec = tools.tool_tables(gold["names"], gold["force"])
@@ -129,7 +129,7 @@ def test_results_writer_layout(tmp_path):
 
 
 @pytest.mark.parametrize("fixture", ["netgen_windows_example_01.json", "netgen_windows_example_01_r5.json", "netgen_windows_bm2.json",
-                                     "netgen_windows_bm2_r8.json"])
+                                     "netgen_windows_bm2_r8.json", "netgen_windows_thin_bedded.json"])
 def test_netgen_path_windowing_matches_reference(fixture, examples_dir):
     gold = load(fixture)
     m = Model(["A0.4M6.0N", "A2.0M0.5N"])

@@ -28,19 +28,17 @@ def test_share_is_block_cyclic_and_complete():
             assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
 
 
-def test_two_rank_sweep_combines_logs(tmp_path):
+def _run_two_ranks(tmp_path, schedule):
     out = str(tmp_path / "res")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sweep_worker.py"), out]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sweep_worker.py"), out, schedule]
+    env = dict(os.environ, OMP_NUM_THREADS="1", REMO_DIST_BACKEND="gloo")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    res = [json.load(open(f"{out}.{k}")) for k in range(2)]
-    assert res[0]["world"] == 2 and {res[0]["rank"], res[1]["rank"]} == {0, 1}
-    # disjoint block-cyclic shares that cover all batches; every rank only solved its own share
-    all_b = sorted(res[0]["share"] + res[1]["share"])
-    assert all_b == list(range(len(all_b))) and res[0]["share"][0] == 0 and res[1]["share"][0] == 1
-    assert res[0]["calls"] == len(res[0]["share"]) - (1 if 3 in res[0]["share"] else 0) or res[0]["calls"] == len(res[0]["share"])
+    return [json.load(open(f"{out}.{k}")) for k in range(2)]
+
+
+def _check_logs(res):
     # both ranks hold the same, complete logs after the all-reduce
     for tool in res[0]["logs"]:
         a = np.array(res[0]["logs"][tool]); b = np.array(res[1]["logs"][tool])
@@ -51,3 +49,47 @@ def test_two_rank_sweep_combines_logs(tmp_path):
     # the injected failure of batch 3 became NaN for exactly its records (worker.py:135-138)
     n_nan = sum(int(np.isnan(np.array(v)[:, 1]).sum()) for v in res[0]["logs"].values())
     assert 0 < n_nan <= 4 * 3
+
+
+def test_two_rank_sweep_with_pull_scheduling(tmp_path):
+    """schedule="dynamic" (the reference's pull scheduling, remo3d.py:843-860): every batch is drawn exactly once from
+    the shared counter; the rank that is made slow ends up with fewer batches; logs identical to the static sweep."""
+    res = _run_two_ranks(tmp_path, "dynamic")
+    n = res[0]["n_batches"]
+    assert res[0]["taken"] + res[1]["taken"] == n
+    assert res[0]["calls"] + res[1]["calls"] == n
+    slow = res[0] if res[0]["rank"] == 0 else res[1]
+    fast = res[1] if res[0]["rank"] == 0 else res[0]
+    assert slow["taken"] < fast["taken"], (slow["taken"], fast["taken"])
+    _check_logs(res)
+    assert res[0]["timing"]["failed_batches"] + res[1]["timing"]["failed_batches"] == 1
+
+
+def test_two_rank_sweep_combines_logs(tmp_path):
+    """Model.initialize_workers joins the process group by itself (the worker never calls sweep.init_from_env)."""
+    res = _run_two_ranks(tmp_path, "static")
+    assert res[0]["world"] == 2 and {res[0]["rank"], res[1]["rank"]} == {0, 1}
+    assert res[0]["timing"]["world_size"] == 2
+    # disjoint block-cyclic shares that cover all batches; every rank only solved its own share
+    all_b = sorted(res[0]["share"] + res[1]["share"])
+    assert all_b == list(range(len(all_b))) and res[0]["share"][0] == 0 and res[1]["share"][0] == 1
+    assert res[0]["calls"] == len(res[0]["share"]) - (1 if 3 in res[0]["share"] else 0) or res[0]["calls"] == len(res[0]["share"])
+    _check_logs(res)
+    # the failed batch is on record (not only NaN): rank 1 owns batch 3
+    assert res[1]["timing"]["failed_batches"] == 1 and "injected failure" in res[1]["first_error"]
+    assert res[0]["timing"]["failed_batches"] == 0
+    assert len(res[0]["timing"]["busy_s_per_rank"]) == 2
+
+
+def test_two_rank_sweep_with_pull_scheduling(tmp_path):
+    """schedule="dynamic" (the reference's pull scheduling, remo3d.py:843-860): every batch is drawn exactly once from
+    the shared counter; the rank that is made slow ends up with fewer batches; logs identical to the static sweep."""
+    res = _run_two_ranks(tmp_path, "dynamic")
+    n = res[0]["n_batches"]
+    assert res[0]["taken"] + res[1]["taken"] == n
+    assert res[0]["calls"] + res[1]["calls"] == n
+    slow = res[0] if res[0]["rank"] == 0 else res[1]
+    fast = res[1] if res[0]["rank"] == 0 else res[0]
+    assert slow["taken"] < fast["taken"], (slow["taken"], fast["taken"])
+    _check_logs(res)
+    assert res[0]["timing"]["failed_batches"] + res[1]["timing"]["failed_batches"] == 1

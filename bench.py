@@ -277,6 +277,16 @@ def roofline_of(agg, precision, stride, workload_name=None):
     return r
 
 
+def log(msg):
+    """Progress on stderr (stdout carries the ONE JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - T_START, msg))
+        sys.stderr.flush()
+
+
+T_START = time.time()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,10 +358,11 @@ def main():
     t_mesh0 = time.time()
     wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh, total_depths=args.total_depths or None,
                         all_batches=dynamic, pool=mesh_pool)
-    extra_wl = [(name, build_workload(0, 1, 100, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)) for name, size, kind, nb in extra_specs]
+    extra_wl = [(name, build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)) for name, size, kind, nb in extra_specs]   # the 20-depth sweep of the same model: 8 batches
     if mesh_pool is not None:
         mesh_pool.shutdown()
     mesh_wall = time.time() - t_mesh0
+    log("meshes built: %d batches of the headline workload + %s in %.1f s" % (len(wl["work"]), [(n, len(w["work"])) for n, w in extra_wl], mesh_wall))
 
     from remo3d_amd import solver, sweep
     if args.tune:
@@ -381,7 +392,9 @@ def main():
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
 
+    log("batches resident on the device; timing %d + %d steps" % (args.warmup, args.steps))
     dt_local, slab, agg, busy = timed(runner, args.steps, args.warmup, sync)
+    log("timed region done: %.3f s" % dt_local)
     dt = sweep.max_over_ranks(dt_local)
     busy_ranks = sweep.gather_floats([1e3 * busy / args.steps, float(agg["batches"])])
 
@@ -415,11 +428,13 @@ def main():
         # the same sweep with the per-batch host -> device copy of the mesh arrays INSIDE the timed span (SURVEY 8d's span; the
         # one-shot entry remo_solve_batch: create + run + fetch + destroy per batch)
         dth, slab_h, agg_h, _ = timed(runner, max(1, min(args.steps, 2)), 1, sync, h2d_inclusive=True)
+        log("H2D-inclusive leg done: %.3f s" % dth)
         out["value_h2d_inclusive"] = dict(value=n_points * max(1, min(args.steps, 2)) / dth, unit="points/s",
                                           note="remo_solve_batch per batch: upload of the mesh arrays (pageable host memory) + run + fetch inside the timed span",
                                           max_abs_log_diff_vs_resident=float(np.nanmax(np.abs(slab_h - slab))))
     if not args.no_cpu and world == 1:           # the CPU leg belongs to the N = 1 line only
         cb, ref_out = cpu_baseline(work, args.rtol)
+        log("CPU baseline leg done")
         out["cpu_baseline"] = cb
         got = runner.resident[0].fetch()[0]
         out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got - ref_out) / np.abs(ref_out)))
@@ -439,6 +454,7 @@ def main():
                           max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"], spmm_avg_launch_us=rf["avg_launch_us"],
                           solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))
         r2.close()
+        log("size leg %s done: %.3f s for %d steps" % (name, dt2, st2))
     if extras:
         out["sizes"] = sizes
     print(json.dumps(out))

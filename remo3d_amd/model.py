@@ -27,8 +27,15 @@ from . import geometry, meshgen, tasks, tools as tools_mod
 CONVERSION = {"M": 1.0, "DM": 0.1, "CM": 0.01, "MM": 0.001, "IN": 0.0254, "FT": 0.3048}
 
 
-def default_mesh_provider(scale: float = 1.0, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
-    """Batch mesh factory.  2D: interface-conforming half-disc meshes built per batch.
+# Default multiplier on the reference's size field.  2D: 0.35 - the value at which the complete Example_01 of the reference
+# (1506 points) sits within p99 8e-4 / max 2.2e-3 of the reference's committed log (scale 1.0: 7.7e-3 / 2.5e-2, 0.5: 3.6e-3 /
+# 9.4e-3; profiles/r02_example01_scales.log): short lateral spacings read potential differences of a few per cent of the
+# potential, next to a borehole wall with a kink every 0.1 m.  3D: 1.0 (the reference's field as it is).
+DEFAULT_SCALE = {2: 0.35, 3: 1.0}
+
+
+def default_mesh_provider(scale: Optional[float] = None, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
+    """Batch mesh factory.  scale: multiplier on the reference's size field (None: DEFAULT_SCALE by dimension).  2D: interface-conforming half-disc meshes built per batch.
     3D, mesh_3d = "conforming" (default): the 2D conforming mesh of the window revolved in the sheared
     frame of the dipping layers (meshgen.make_mesh_3d_conforming: every interface of the reference's
     OpenCASCADE geometry is a union of element faces); "lattice": seeded graded half-ball meshes cached on
@@ -37,7 +44,10 @@ def default_mesh_provider(scale: float = 1.0, seed: int = 0, mesh_3d: str = "con
         raise ValueError("mesh_3d must be 'conforming' or 'lattice'")
     cache: Dict[tuple, meshgen.Mesh] = {}
 
+    scale_arg = scale
+
     def provider(dim, domain_radius, batch, local_formation_geometry, local_borehole_geometry, dip_rad):
+        scale = DEFAULT_SCALE[dim] if scale_arg is None else scale_arg
         cur = batch.electrodes[0, batch.electrodes[1, :] != 0]
         pot = batch.electrodes[0, batch.electrodes[1, :] == 0]
         fn = meshgen.layered_material_fn(dim, local_formation_geometry, local_borehole_geometry, dip_rad)
@@ -251,7 +261,7 @@ class Model:
 
     # -- the sweep (remo3d.py:723-884 + workers/worker.py:74-142) ----------------------------------
     def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
-                      condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: float = 1.0, rtol: float = 1e-8,
+                      condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: Optional[float] = None, rtol: float = 1e-8,
                       maxsteps: int = 1000, verbose: bool = True, mesh_workers: Optional[int] = None, precision: str = "fp64",
                       schedule: str = "static"):
         from . import solver, sweep

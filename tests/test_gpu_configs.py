@@ -115,23 +115,28 @@ def test_example_02_complete_log(examples_dir):
 @pytest.mark.parametrize("logs,formation,shifted", [("Logs 1", "Formation_model_1.txt", False), ("Logs 2", "Formation_model_2.txt", False),
                                                     ("Logs 3", "Formation_model_1.txt", True), ("Logs 4", "Formation_model_2.txt", True)])
 def test_thin_bedded_logs(logs, formation, shifted, examples_dir):
-    """The reference's thin-bedded benchmark (140 / 201 layers of ~0.125 m, 81 depths x 4 tools).  Logs 3 / 4 were computed at
-    the misaligned depths of Logs_depth_shifts.txt.  The reference did not record its settings (defaults assumed).  The short
-    tools agree at the level of Example_01; the 9 m lateral A8.0M1.0N carries a systematic offset of the reference's log
-    (DESIGN.md section 4): asserted per tool."""
+    """The reference's thin-bedded benchmark (140 / 201 layers of ~0.125 m, 81 depths x 4 tools incl. the 9 m lateral
+    A8.0M1.0N); Logs 3 / 4 were computed at the misaligned depths of Logs_depth_shifts.txt.  The reference did not record the
+    settings of these runs.  They are domain_radius = 15, batch_size = 10: with the defaults (50 / 5) the long lateral differs
+    from the reference's log by a sawtooth in depth that is linear in the position of the current electrode inside a batch of
+    TEN depths (the image of an off-centre source in a grounded sphere only 15 m away), and a scan over the two settings
+    (tools/thin_bedded_settings_scan.py, profiles/r02_thin_bedded_settings_scan.log) takes the median difference of that tool
+    from 2.5e-2 (R = 50) through 1.3e-2 (20) and 7.7e-3 (17.5) to 2.8e-4 at R = 15 - where ALL four tools agree with the
+    reference's `%.4f` log to a few 1e-5."""
     base = os.path.join(examples_dir, "Benchmark models", "Thin-bedded model")
     depths = np.arange(0, 20.01, 0.25)
     if shifted:
         depths = np.loadtxt(os.path.join(base, "Logs", "Logs_depth_shifts.txt"), skiprows=2)[:, 1]
     out, rel, signed = _compare_with_log(TB_TOOLS, depths, os.path.join(base, "Logs", logs, "Results_1.txt"), os.path.join(base, "Formation", formation),
-                                         os.path.join(base, "Borehole", "Borehole_model_correct_rm.txt"))
+                                         os.path.join(base, "Borehole", "Borehole_model_correct_rm.txt"), domain_radius=15, batch_size=10)
+    out["settings"] = dict(domain_radius=15, batch_size=10)
     out["A8.0M1.0N_signed_by_depth"] = [[float(d), float(s)] for d, s in zip(depths, signed[3])]
     _record("thin_bedded_%s.json" % logs.replace(" ", "_"), out)
-    print(logs, {t: (out["per_tool"][t]["median"], out["per_tool"][t]["max"]) for t in TB_TOOLS})
+    print(logs, {t: (out["per_tool"][t]["median"], out["per_tool"][t]["p99"], out["per_tool"][t]["max"]) for t in TB_TOOLS})
     assert out["nan"] == 0 and out["failed_batches"] == 0
-    lim = {"A0.4M6.0N": (1.5e-3, 1e-2), "A1.62M6.0N": (4e-3, 2e-2), "A4.0M0.5N": (8e-3, 4e-2), "A8.0M1.0N": (4e-2, 8e-2)}
+    assert out["median"] < 2e-4 and out["p90"] < 1e-3 and out["max"] < 1e-2, out
     for t in TB_TOOLS:
-        assert out["per_tool"][t]["median"] < lim[t][0] and out["per_tool"][t]["max"] < lim[t][1], (t, out["per_tool"][t])
+        assert out["per_tool"][t]["median"] < 5e-4, (t, out["per_tool"][t])
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -259,10 +264,10 @@ def test_dipping_interface_image_solution_3d(precision, gpu_ctx):
     for scale in (2.0, 1.0):
         mesh, sigma, zs, exact = _dipping_interface_case(scale)
         outs, st, rc = gpu_ctx.solve_batch(mesh, sigma, [([0.0], [1.0])], [list(zs)], solver.make_opts(rtol=1e-10, precision=precision, maxsteps=5000))
-        assert rc == 0
+        assert rc == 0, (rc, st["pcg_steps"], st["relres"][:1], st["refinement_cycles"])
         got = outs[0]
         d_got, d_ex = got[:-1] - got[1:], exact[:-1] - exact[1:]
-        errs[scale] = (float(np.max(np.abs(d_got - d_ex) / np.abs(d_ex))), int(mesh.n_elems), int(st["n_free"]))
+        errs[scale] = (float(np.max(np.abs(d_got - d_ex) / np.abs(d_ex))), int(mesh.n_elems), int(st["n_free"]), int(st["pcg_steps"]))
     _record("dipping_interface_%s.json" % precision, {str(k): v for k, v in errs.items()})
     print("dipping interface, max rel error of potential differences by mesh scale:", errs)
     assert errs[1.0][0] < 5e-3, errs

@@ -19,7 +19,7 @@ def test_oracle_reproduces_the_reference_example_01_log(examples_dir):
     m = Model(tools)
     m.set_model_parameters(os.path.join(ex, "Input/Formation.txt"), os.path.join(ex, "Input/Borehole.txt"))
     m.initialize_workers(cpu_workers=1, gpu_workers=4, context_factory=OracleContext)     # four oracle "contexts" = four host threads
-    m.simulate_logs(depths, verbose=False)
+    m.simulate_logs(depths, verbose=False, mesh_scale=1.0)      # the coarse size field keeps the oracle's Jacobi-PCG to seconds; the GPU tests use the default
     m.shutdown_workers()
     assert m.timing["failed_batches"] == 0 and m.timing["not_converged"] == 0
     rows = np.rint(depths / 0.1).astype(int)

@@ -101,15 +101,20 @@ def test_example_01_complete_log(examples_dir):
 
 
 def test_example_02_complete_log(examples_dir):
-    """Example_02 of the reference: the same model with domain_radius 25, batch_size 10, Netgen-path windowing."""
+    """Example_02 of the reference: the same model, batch_size 10, Netgen-path windowing, borehole given by diameter.
+    Example_02.py also passes domain_radius = 25, but the log the reference COMMITTED was not computed with it: it agrees with
+    its own Example_01 log (R = 50) to median 2e-5 / max 3.1e-4, and with our runs at R = 50 to median 6e-5 / p99 8e-4, against
+    4.3e-4 / 3.4e-3 at R = 25 and worse at 20 or 30 (tools/example02_settings_scan.py, profiles/r02_example02_settings_scan.log).
+    Compared here at the radius the numbers were evidently made with."""
     ex = os.path.join(examples_dir, "Example_02")
     out, rel, _ = _compare_with_log(EX01_TOOLS, np.arange(0, 25.1, 0.1), os.path.join(ex, "Output/Results_2024_08_17__19_03_42/Results_1.txt"),
                                     os.path.join(ex, "Input/Formation.txt"), os.path.join(ex, "Input/Borehole.txt"),
-                                    borehole_geometry_type="diameter", dip=0, mesh_generator="netgen", domain_radius=25, batch_size=10)
+                                    borehole_geometry_type="diameter", dip=0, mesh_generator="netgen", domain_radius=50, batch_size=10)
+    out["settings"] = dict(domain_radius=50, batch_size=10, note="Example_02.py says domain_radius=25; the committed log does not")
     _record("example02_parity.json", out)
     print("Example_02:", {k: out[k] for k in ("median", "p90", "p99", "max", "seconds")})
     assert out["points"] == 1506 and out["nan"] == 0 and out["failed_batches"] == 0
-    assert out["median"] < 5e-4 and out["p99"] < 2e-3 and out["max"] < 5e-3, out
+    assert out["median"] < 3e-4 and out["p99"] < 1e-3 and out["max"] < 5e-3, out
 
 
 @pytest.mark.parametrize("logs,formation,shifted", [("Logs 1", "Formation_model_1.txt", False), ("Logs 2", "Formation_model_2.txt", False),
@@ -263,7 +268,10 @@ def test_dipping_interface_image_solution_3d(precision, gpu_ctx):
     errs = {}
     for scale in (2.0, 1.0):
         mesh, sigma, zs, exact = _dipping_interface_case(scale)
-        outs, st, rc = gpu_ctx.solve_batch(mesh, sigma, [([0.0], [1.0])], [list(zs)], solver.make_opts(rtol=1e-10, precision=precision, maxsteps=5000))
+        # (the degenerate "borehole" of radius 0 leaves needle elements along the axis: ~1900 PCG steps in fp64; the fp32 inner solver
+        # of the mixed mode loses conjugacy on such a system and is asked for the reference's default tolerance only)
+        rtol = 1e-10 if precision == "fp64" else 1e-8
+        outs, st, rc = gpu_ctx.solve_batch(mesh, sigma, [([0.0], [1.0])], [list(zs)], solver.make_opts(rtol=rtol, precision=precision, maxsteps=20000))
         assert rc == 0, (rc, st["pcg_steps"], st["relres"][:1], st["refinement_cycles"])
         got = outs[0]
         d_got, d_ex = got[:-1] - got[1:], exact[:-1] - exact[1:]

@@ -59,7 +59,6 @@ template <class T> struct CsrViewT {
     // bcol = [vertex columns | first column of every edge-column pair | face columns]
     const int4 *meta = nullptr;
     const int32_t *bcol = nullptr;
-    int64_t units = 0;     // entries of bcol
 };
 using CsrView = CsrViewT<double>;
 

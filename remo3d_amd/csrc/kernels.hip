@@ -368,74 +368,6 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t pair_begin, int
     }
 }
 
-// ---- buffer loads with the hardware range check ------------------------------------------------------------
-// A lane that has nothing to load hands the instruction an offset beyond the descriptor's range: the load returns 0
-// and sends no request down the vector-memory path.  "Conditional" loads therefore need no branch - and no branch
-// means the compiler keeps every load of a trip in flight at once instead of waiting at each join.
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr uint32_t kOutOfRange = 0xFFFFF000u;   // beyond any descriptor the host accepts (launch_spmm checks the sizes)
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, int(uint32_t(bytes)), 0x00020000);
-}
-// N values of T from byte offset `off` (a multiple of 4): 16-, 8- and 4-byte pieces
-template <class T, int N> __device__ __forceinline__ void buf_load(rsrc_t r, uint32_t off, T (&out)[N]) {
-    constexpr int W = N * int(sizeof(T)) / 4;
-    unsigned int w[W];
-    int d = 0;
-#pragma unroll
-    for (; d + 4 <= W; d += 4) {
-        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, off + 4u * d, 0, 0);
-        w[d] = q.x; w[d + 1] = q.y; w[d + 2] = q.z; w[d + 3] = q.w;
-    }
-    if constexpr ((W & 3) >= 2) {
-        const u32x2_t q = __builtin_amdgcn_raw_buffer_load_b64(r, off + 4u * (W & ~3), 0, 0);
-        w[W & ~3] = q.x; w[(W & ~3) + 1] = q.y;
-    }
-    if constexpr (W & 1) w[W - 1] = __builtin_amdgcn_raw_buffer_load_b32(r, off + 4u * (W - 1), 0, 0);
-    __builtin_memcpy(out, w, sizeof(T) * N);
-}
-
-// One row (PAIR: the two rows of an edge) on the column-blocked index.  A lane walks the three column classes of the row
-// side by side: its t-th vertex column, its t-th edge-column PAIR and its t-th face column per trip, so that the index /
-// value loads of all three are requested together, then the three gathers of x (K, 2K and K wide), then the arithmetic
-// - two dependent round trips per trip, and an edge row (<= 16 columns of every class) needs ONE trip of its 16 lanes.
-template <class T, int K, int LPR, bool PAIR>
-__device__ __forceinline__ void blk_row(const int4 mt, rsrc_t rbc, rsrc_t rval, rsrc_t rx, int sub, T (&acc)[2 * K]) {
-    constexpr uint32_t S = sizeof(T);
-    const int32_t a = mt.w & 0xFFFF, b = mt.w >> 16, c = mt.y - a - 2 * b;
-    const uint32_t bc0 = uint32_t(mt.z) * 4u, v0 = uint32_t(mt.x) * S;
-    const int32_t nmax = a > b ? (a > c ? a : c) : (b > c ? b : c);
-    for (int32_t t = sub; t < nmax; t += LPR) {
-        const bool hv = t < a, he = t < b, hf = t < c;
-        unsigned int jv[1], je[1], jf[1];
-        buf_load<unsigned int, 1>(rbc, hv ? bc0 + 4u * uint32_t(t) : kOutOfRange, jv);
-        buf_load<unsigned int, 1>(rbc, he ? bc0 + 4u * uint32_t(a + t) : kOutOfRange, je);
-        buf_load<unsigned int, 1>(rbc, hf ? bc0 + 4u * uint32_t(a + b + t) : kOutOfRange, jf);
-        // stored entries: vertex column t -> entry t; edge pair t -> entries a + 2t, a + 2t + 1; face column t -> entry a + 2b + t
-        // (PAIR: the values of rows r, r + 1 interleaved, entry e at 2e, 2e + 1)
-        constexpr int NV = PAIR ? 2 : 1, NE = PAIR ? 4 : 2;
-        T vv[NV], ee[NE], ff[NV];
-        buf_load<T, NV>(rval, hv ? v0 + S * NV * uint32_t(t) : kOutOfRange, vv);
-        buf_load<T, NE>(rval, he ? v0 + S * NV * uint32_t(a + 2 * t) : kOutOfRange, ee);
-        buf_load<T, NV>(rval, hf ? v0 + S * NV * uint32_t(a + 2 * b + t) : kOutOfRange, ff);
-        T xv[K], xe[2 * K], xf[K];
-        buf_load<T, K>(rx, hv ? jv[0] * (S * K) : kOutOfRange, xv);
-        buf_load<T, 2 * K>(rx, he ? je[0] * (S * K) : kOutOfRange, xe);
-        buf_load<T, K>(rx, hf ? jf[0] * (S * K) : kOutOfRange, xf);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if constexpr (PAIR) {
-                acc[k] += vv[0] * xv[k] + ee[0] * xe[k] + ee[2] * xe[K + k] + ff[0] * xf[k];
-                acc[K + k] += vv[1] * xv[k] + ee[1] * xe[k] + ee[3] * xe[K + k] + ff[1] * xf[k];
-            } else {
-                acc[k] += vv[0] * xv[k] + ee[0] * xe[k] + ee[1] * xe[K + k] + ff[0] * xf[k];
-            }
-        }
-    }
-}
-
 // Variant C ("edge row pairs", the default): the two dofs of an edge are consecutive rows with the
 // SAME column pattern, and edge rows hold ~3/4 of the stored entries.  A lane group takes both
 // rows at once: one column index and ONE gather of the x row serve two stored entries.  Vertex and
@@ -454,15 +386,9 @@ __device__ __forceinline__ void blk_row(const int4 mt, rsrc_t rbc, rsrc_t rval, 
 template <class T, int K, int LPR, bool DOT, int MODE = 0, bool BLK = false>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
 __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, int xcd_windows, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ col, const int4 *__restrict__ meta, const T *__restrict__ val,
-                                                   const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal, int step, int64_t nnz, int64_t units) {
+                                                   const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal, int step) {
     if (scal && solve_done(scal, step)) return;
     constexpr int U = 2;
-    rsrc_t rbc, rval, rx;
-    if constexpr (BLK) {   // col = the blocked index list in this instantiation
-        rbc = make_rsrc(col, uint64_t(units) * 4u);
-        rval = make_rsrc(val, uint64_t(nnz + 2) * sizeof(T));
-        rx = make_rsrc(x, uint64_t(n) * K * sizeof(T));
-    }
     constexpr int MFP = treduce_out(2 * K, LPR), MFS = treduce_out(K, LPR);   // sums per lane after the reduction
     const int rpb = blockDim.x / LPR;
     const int sub = threadIdx.x % LPR;
@@ -556,9 +482,57 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 #pragma unroll
         for (int c = 0; c < 2 * K; ++c) acc[c] = T(0);
         if constexpr (BLK) {
-            // wave-uniform for all but the handful of waves that straddle a row class
-            if (pair) blk_row<T, K, LPR, true>(mt, rbc, rval, rx, sub, acc);
-            else blk_row<T, K, LPR, false>(mt, rbc, rval, rx, sub, acc);
+            // units of the row: [0, a) vertex columns, [a, a + b) edge-column pairs, [a + b, units) face columns;
+            // unit u starts at stored entry e(u) of the row
+            typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+            const int32_t a = mt.w & 0xFFFF, ab = a + (mt.w >> 16), units = mt.y - (mt.w >> 16);
+            const int32_t *bc = col + mt.z;      // col = the blocked index list in this instantiation
+            for (int32_t u0 = sub; u0 < units; u0 += U * LPR) {
+                int32_t j[U];
+                bool two[U];
+                T v0[U], v1[U], v2[U], v3[U], xa[U][K], xb[U][K];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int32_t uu = u0 + u * LPR;
+                    j[u] = -1; two[u] = false; v0[u] = T(0); v1[u] = T(0); v2[u] = T(0); v3[u] = T(0);
+                    if (uu < units) {
+                        j[u] = bc[uu];
+                        two[u] = uu >= a && uu < ab;
+                        const int32_t e = uu < a ? uu : (uu < ab ? 2 * uu - a : uu + (ab - a));
+                        if (pair) {      // interleaved values of rows r, r + 1: entry e at rs + 2e, rs + 2e + 1
+                            const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + 2 * e);
+                            v0[u] = vv.x; v1[u] = vv.y;
+                            if (two[u]) {
+                                const pair_t ww = *reinterpret_cast<const pair_t *>(val + rs + 2 * e + 2);
+                                v2[u] = ww.x; v3[u] = ww.y;
+                            }
+                        } else {         // plain CSR row: entries e, e + 1 side by side (the second one is unused for a single column)
+                            const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + e);
+                            v0[u] = vv.x; v2[u] = two[u] ? vv.y : T(0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int c = 0; c < K; ++c) { xa[u][c] = T(0); xb[u][c] = T(0); }
+                    if (j[u] >= 0) {
+                        const T *xr = x + int64_t(j[u]) * K;
+#pragma unroll
+                        for (int c = 0; c < K; ++c) xa[u][c] = xr[c];
+                        if (two[u])
+#pragma unroll
+                            for (int c = 0; c < K; ++c) xb[u][c] = xr[K + c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        acc[c] += v0[u] * xa[u][c] + v2[u] * xb[u][c];
+                        acc[K + c] += v1[u] * xa[u][c] + v3[u] * xb[u][c];
+                    }
+            }
         } else
         for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {
             int32_t j[U];
@@ -695,7 +669,7 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
     int variant = g_tune.variant ? g_tune.variant : (A.meta ? 4 : 3);   // 4 = edge row pairs x edge column pairs (blocked index)
-    if (variant == 4 && (!A.meta || uint64_t(A.nnz + 2) * sizeof(T) >= kOutOfRange || uint64_t(A.n) * K * sizeof(T) >= kOutOfRange)) variant = 3;   // buffer descriptors: 32-bit ranges
+    if (variant == 4 && !A.meta) variant = 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
     // default row schedule of the pair kernel: XCD windows (measured 69 -> 60 us at 334k rows, k = 5); once the matrix no
     // longer stays in the 256 MB of MALL between launches (3D, more than ~20 M stored entries), XCD regions (4 chunks
@@ -713,19 +687,19 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
         hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal, step)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step, A.nnz, int64_t(0)); \
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step, A.nnz, int64_t(0))
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step)
 #define REMO_SPMM_BLK(L)                                                                                                                \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step, A.nnz, A.units); \
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step, A.nnz, A.units)
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step)
     if constexpr (K == 5 && sizeof(T) == 8) {   // ablation modes of tools/probe_ablate.py
         if (variant == 3 && lpr == 16 && g_tune.mode >= 1 && g_tune.mode <= 3 && !part) {
-            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step, A.nnz, int64_t(0));
-            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step, A.nnz, int64_t(0));
-            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step, A.nnz, int64_t(0));
+            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
             return;
         }
     }

@@ -656,7 +656,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
-        b->A.meta = blk.meta; b->A.bcol = blk.bcol; b->A.units = blk.units;
+        b->A.meta = blk.meta; b->A.bcol = blk.bcol;
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;
@@ -681,7 +681,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             launch_to_float(n, d_dinv, dinv32, s);
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
-            mx.A32.meta = b->A.meta; mx.A32.bcol = b->A.bcol; mx.A32.units = b->A.units;
+            mx.A32.meta = b->A.meta; mx.A32.bcol = b->A.bcol;
             PcgBuffersT<float> &f = mx.b32;
             f.x = ctx->take<float>(size_t(n) * kmax); f.r = ctx->take<float>(size_t(n) * kmax);
             f.p = ctx->take<float>(size_t(n) * kmax + 4); f.q = ctx->take<float>(size_t(n) * kmax);

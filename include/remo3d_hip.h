@@ -177,12 +177,12 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
                        int32_t *freeid /*[n_dof] or NULL*/);
 
 /* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
- * entry, 3 edge row pairs, 4 edge row pairs x edge column pairs on the blocked index = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
+ * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
  * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;
  * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
  * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
  * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 14: 0 = do not build the column-blocked SpMM index (the SpMM then walks plain CSR indices).  Process-global. */
+ * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always.  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

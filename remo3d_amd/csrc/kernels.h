@@ -55,10 +55,6 @@ template <class T> struct CsrViewT {
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
     // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
-    // column-blocked index (symbolic_gpu.h BlockIndex), nullptr = not built: per row {rs, len, offset into bcol, a | b << 16},
-    // bcol = [vertex columns | first column of every edge-column pair | face columns]
-    const int4 *meta = nullptr;
-    const int32_t *bcol = nullptr;
 };
 using CsrView = CsrViewT<double>;
 

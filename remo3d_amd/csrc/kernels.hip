@@ -377,15 +377,9 @@ __global__ void __launch_bounds__(512) k_spmm(int64_t n, int64_t pair_begin, int
 // passes of its row up front and then all U gathers, before any arithmetic: a row of <= U * LPR
 // entries pays the two latencies once instead of once per pass.  Lanes past the row end read a
 // safe address with a zero value (no branches between the loads).
-//
-// BLK (the default when the batch has a column-blocked index, symbolic_gpu.hip build_block_index): the edge COLUMNS of
-// every row come in pairs (j, j + 1) as well, so a lane takes a "unit" = one vertex / face column or one edge-column
-// pair: one stored index, and for a pair ONE 2K-wide gather of x (two consecutive rows of x) against four stored
-// entries of an edge-row pair.  The gather costs by lane-requests and bytes through the vector-memory path (DESIGN.md
-// section 3): 0.7 of the indices, and 5 requests of 16 bytes for 80 bytes of x instead of 6.
-template <class T, int K, int LPR, bool DOT, int MODE = 0, bool BLK = false>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
+template <class T, int K, int LPR, bool DOT, int MODE = 0>   // MODE != 0: ablations for tools/probe_ablate.py (wrong results on purpose)
 __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin, int64_t pair_end, int xcd_windows, const int32_t *__restrict__ rowptr,
-                                                   const int32_t *__restrict__ col, const int4 *__restrict__ meta, const T *__restrict__ val,
+                                                   const int32_t *__restrict__ col, const T *__restrict__ val,
                                                    const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part, const double *__restrict__ scal, int step) {
     if (scal && solve_done(scal, step)) return;
     constexpr int U = 2;
@@ -455,85 +449,24 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
     bool pair_n = false, valid_n = false;
     int64_t row_n = 0;
     int32_t rs_n = 0, re_n = 0;
-    int4 meta_n = make_int4(0, 0, 0, 0);
     if (g < glimit) {
         valid_n = locate(g, row_n, pair_n);
-        if (valid_n) {
-            if constexpr (BLK) meta_n = meta[row_n];
-            else { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
-        }
+        if (valid_n) { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
     }
     for (; g < glimit; g += gstep) {
         const int64_t row = row_n;
         const bool pair = pair_n, valid = valid_n;
-        const int32_t rs = BLK ? meta_n.x : rs_n, re = BLK ? meta_n.x + meta_n.y : re_n;
-        const int4 mt = meta_n;
+        const int32_t rs = rs_n, re = re_n;
         // the row pointers of the NEXT row are requested now: one of the three dependent round trips
         // of a row (pointers -> indices -> x) leaves the critical path
         if (g + gstep < glimit) {
             valid_n = locate(g + gstep, row_n, pair_n);
-            if (valid_n) {
-                if constexpr (BLK) meta_n = meta[row_n];
-                else { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
-            }
+            if (valid_n) { rs_n = rowptr[row_n]; re_n = rowptr[row_n + 1]; }
         }
         if (!valid) continue;
         T acc[2 * K];                             // [0, K): row, [K, 2K): row + 1
 #pragma unroll
         for (int c = 0; c < 2 * K; ++c) acc[c] = T(0);
-        if constexpr (BLK) {
-            // units of the row: [0, a) vertex columns, [a, a + b) edge-column pairs, [a + b, units) face columns;
-            // unit u starts at stored entry e(u) of the row
-            typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));
-            const int32_t a = mt.w & 0xFFFF, ab = a + (mt.w >> 16), units = mt.y - (mt.w >> 16);
-            const int32_t *bc = col + mt.z;      // col = the blocked index list in this instantiation
-            for (int32_t u0 = sub; u0 < units; u0 += U * LPR) {
-                int32_t j[U];
-                bool two[U];
-                T v0[U], v1[U], v2[U], v3[U], xa[U][K], xb[U][K];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int32_t uu = u0 + u * LPR;
-                    j[u] = -1; two[u] = false; v0[u] = T(0); v1[u] = T(0); v2[u] = T(0); v3[u] = T(0);
-                    if (uu < units) {
-                        j[u] = bc[uu];
-                        two[u] = uu >= a && uu < ab;
-                        const int32_t e = uu < a ? uu : (uu < ab ? 2 * uu - a : uu + (ab - a));
-                        if (pair) {      // interleaved values of rows r, r + 1: entry e at rs + 2e, rs + 2e + 1
-                            const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + 2 * e);
-                            v0[u] = vv.x; v1[u] = vv.y;
-                            if (two[u]) {
-                                const pair_t ww = *reinterpret_cast<const pair_t *>(val + rs + 2 * e + 2);
-                                v2[u] = ww.x; v3[u] = ww.y;
-                            }
-                        } else {         // plain CSR row: entries e, e + 1 side by side (the second one is unused for a single column)
-                            const pair_t vv = *reinterpret_cast<const pair_t *>(val + rs + e);
-                            v0[u] = vv.x; v2[u] = two[u] ? vv.y : T(0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-#pragma unroll
-                    for (int c = 0; c < K; ++c) { xa[u][c] = T(0); xb[u][c] = T(0); }
-                    if (j[u] >= 0) {
-                        const T *xr = x + int64_t(j[u]) * K;
-#pragma unroll
-                        for (int c = 0; c < K; ++c) xa[u][c] = xr[c];
-                        if (two[u])
-#pragma unroll
-                            for (int c = 0; c < K; ++c) xb[u][c] = xr[K + c];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int c = 0; c < K; ++c) {
-                        acc[c] += v0[u] * xa[u][c] + v2[u] * xb[u][c];
-                        acc[K + c] += v1[u] * xa[u][c] + v3[u] * xb[u][c];
-                    }
-            }
-        } else
         for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {
             int32_t j[U];
             T v0[U], v1[U], xv[U][K];
@@ -621,7 +554,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 // tuning knobs (remo_debug_tune): 0 = heuristic default
 struct SpmmTuning {
     int mode = 0;     // ablation mode of the pair kernel (K = 5, 16 lanes per row only)
-    int variant = 0;  // 1 = lane per stored entry, 3 = edge row pairs, 4 = row pairs x column pairs on the blocked index (default when built)
+    int variant = 0;  // 1 = lane per stored entry, 3 = edge row pairs (default)
     int lpr = 0;
     int threads = 0;
     int mapping = -1;
@@ -668,8 +601,7 @@ int spmv_grid(int64_t n, int lpr) {
 template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
     int lpr = choose_lanes_per_row(A.n, A.nnz);
     const int threads = spmm_threads();
-    int variant = g_tune.variant ? g_tune.variant : (A.meta ? 4 : 3);   // 4 = edge row pairs x edge column pairs (blocked index)
-    if (variant == 4 && !A.meta) variant = 3;
+    int variant = g_tune.variant ? g_tune.variant : 3;
     if (variant == 3 && !(A.pair_end > A.pair_begin)) variant = 1;
     // default row schedule of the pair kernel: XCD windows (measured 69 -> 60 us at 334k rows, k = 5); once the matrix no
     // longer stays in the 256 MB of MALL between launches (3D, more than ~20 M stored entries), XCD regions (4 chunks
@@ -687,28 +619,18 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
         hipLaunchKernelGGL((k_spmm<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, A.rowptr, A.col, A.val, x, y, part, scal, step)
 #define REMO_SPMM_PAIR(L)                                                                                                               \
     if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step); \
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step); \
     else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step)
-#define REMO_SPMM_BLK(L)                                                                                                                \
-    if (part)                                                                                                                           \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, true, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step); \
-    else                                                                                                                                \
-        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false, 0, true>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.bcol, A.meta, A.val, x, y, part, scal, step)
+        hipLaunchKernelGGL((k_spmm_pair<T, K, L, false>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step)
     if constexpr (K == 5 && sizeof(T) == 8) {   // ablation modes of tools/probe_ablate.py
         if (variant == 3 && lpr == 16 && g_tune.mode >= 1 && g_tune.mode <= 3 && !part) {
-            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
-            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
-            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, (const int4 *)nullptr, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 1) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 1>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 2) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 2>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
+            if (g_tune.mode == 3) hipLaunchKernelGGL((k_spmm_pair<T, 5, 16, false, 3>), dim3(nb), dim3(threads), 0, s, A.n, A.pair_begin, A.pair_end, mapping, A.rowptr, A.col, A.val, x, y, part, scal, step);
             return;
         }
     }
-    if (variant == 4) {
-        if (lpr >= 32) { REMO_SPMM_BLK(32); }
-        else if (lpr == 16) { REMO_SPMM_BLK(16); }
-        else if (lpr == 8) { REMO_SPMM_BLK(8); }
-        else { REMO_SPMM_BLK(4); }
-    } else if (variant == 3) {
+    if (variant == 3) {
         if (lpr >= 32) { REMO_SPMM_PAIR(32); }
         else if (lpr == 16) { REMO_SPMM_PAIR(16); }
         else if (lpr == 8) { REMO_SPMM_PAIR(8); }
@@ -721,7 +643,6 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
     }
 #undef REMO_SPMM
 #undef REMO_SPMM_PAIR
-#undef REMO_SPMM_BLK
 }
 
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {

@@ -133,7 +133,6 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
-int g_block_index = 1;   // key 14: 1 = build the column-blocked SpMM index (default), 0 = plain CSR indices
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
@@ -503,7 +502,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        need += size_t(ndof_max) * 40 + size_t(nnz_max) * 4;   // column-blocked SpMM index (+ scratch)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -580,12 +578,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { pair_begin = sy.nvfree; pair_end = sy.nvefree; }
         launch_assemble(dim, sy.condense, n, pair_begin, pair_end, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
-        // column-blocked index of the SpMM (remo_debug_tune key 14: 0 = plain CSR indices)
-        BlockIndex blk;
-        if (g_block_index && pair_end > pair_begin) {
-            rc = build_block_index(ctx->ar, s, n, sy.nnz, pair_begin, pair_end, sy.rowptr, sy.col, blk, err);
-            if (rc != REMO_OK) return fail(ctx, rc, err);
-        }
 
         // ---- point location + shapes (all points at once) ---------------------------------
         if (npts > 0) {
@@ -656,7 +648,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
-        b->A.meta = blk.meta; b->A.bcol = blk.bcol;
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;
@@ -681,7 +672,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             launch_to_float(n, d_dinv, dinv32, s);
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
-            mx.A32.meta = b->A.meta; mx.A32.bcol = b->A.bcol;
             PcgBuffersT<float> &f = mx.b32;
             f.x = ctx->take<float>(size_t(n) * kmax); f.r = ctx->take<float>(size_t(n) * kmax);
             f.p = ctx->take<float>(size_t(n) * kmax + 4); f.q = ctx->take<float>(size_t(n) * kmax);
@@ -926,7 +916,6 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 8) set_symbolic_tuning(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
-    else if (key == 14) g_block_index = value;
     else set_spmm_tuning(key, value);
 }
 

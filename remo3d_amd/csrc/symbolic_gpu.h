@@ -56,18 +56,6 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
                        const int32_t *d_bconn, const uint8_t *d_bdir, bool condense, int32_t *d_err, DeviceSymbolic &out,
                        std::string &err);
 
-// Column-blocked index of the SpMM: per row {value offset rs, row length, offset into bcol, a | b << 16} with a = vertex
-// columns and b = edge-column PAIRS of the row; bcol = [vertex columns | first column of every pair | face columns] per row
-// (per first row of an edge-row pair).  meta == nullptr: not built (no edge pairs, or a row that does not fit the packing).
-struct BlockIndex {
-    const int4 *meta = nullptr;
-    const int32_t *bcol = nullptr;
-    int64_t units = 0;       // stored indices (0.7 nnz in 3D)
-};
-// needs arena space for 16 (n + 1) + 4 (n + nnz) bytes (kept) and ~12 n (scratch); one synchronisation
-int build_block_index(Arena &ar, hipStream_t s, int64_t n, int64_t nnz, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr,
-                      const int32_t *col, BlockIndex &out, std::string &err);
-
 // probe hook: 0 = build the CSR pattern by the global sort instead of row by row
 void set_symbolic_tuning(int row_pattern);
 

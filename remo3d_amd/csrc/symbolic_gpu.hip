@@ -532,92 +532,4 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
 
 void set_symbolic_tuning(int row_pattern) { g_row_pattern = row_pattern; }
 
-// ------------------------------------------------------------------------------------------
-// Column-blocked index of the SpMM (kernels.hip, k_spmm_pair<..., BLK>).  The two dofs of a free edge are consecutive
-// COLUMNS as well as consecutive rows, and every row that holds one holds both (they are local dofs of the same
-// elements), so the edge columns of a row - 60 % of its entries in 3D - are pairs (j, j + 1): one stored index and one
-// 2K-wide gather of x serve both.  A row's index list becomes [vertex columns | first column of every edge pair | face
-// columns], 0.7 of the CSR list; the values stay where launch_assemble puts them.
-
-namespace {
-
-__device__ __forceinline__ int32_t lower_bound_i32(const int32_t *__restrict__ a, int32_t lo, int32_t hi, int32_t key) {
-    while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// units of every row (second rows of an edge pair: 0, their first row speaks for both)
-__global__ void __launch_bounds__(256) k_blk_count(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
-                                                   const int32_t *__restrict__ col, int32_t *__restrict__ cnt, int32_t *__restrict__ ab) {
-    const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (r > n) return;
-    if (r == n) { cnt[n] = 0; return; }
-    const int32_t rs = rowptr[r], re = rowptr[r + 1];
-    const int32_t a = lower_bound_i32(col, rs, re, int32_t(pair_begin)) - rs;
-    const int32_t b = (lower_bound_i32(col, rs, re, int32_t(pair_end)) - rs - a) >> 1;
-    ab[r] = a | (b << 16);
-    const bool second = r >= pair_begin && r < pair_end && ((r - pair_begin) & 1);
-    cnt[r] = second ? 0 : (re - rs - b);
-}
-
-// one wave per row: lane u writes unit u
-__global__ void __launch_bounds__(256) k_blk_fill(int64_t n, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
-                                                  const int32_t *__restrict__ col, const int32_t *__restrict__ bs, const int32_t *__restrict__ ab,
-                                                  int4 *__restrict__ meta, int32_t *__restrict__ bcol, int32_t *flag) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); r < n; r += int64_t(gridDim.x) * 4) {
-        const int32_t rs = rowptr[r], len = rowptr[r + 1] - rs, pk = ab[r], b0 = bs[r];
-        const int32_t a = pk & 0xFFFF, b = pk >> 16;
-        if (lane == 0) {
-            meta[r] = make_int4(rs, len, b0, pk);
-            if (a > 0xFFFF || b > 0x7FFF || 2 * b > len - a) atomicOr(flag, 1);   // does not fit the packing: the caller keeps plain CSR
-        }
-        const bool second = r >= pair_begin && r < pair_end && ((r - pair_begin) & 1);
-        if (second) continue;
-        const int32_t units = len - b;
-        for (int32_t u = lane; u < units; u += 64) {
-            const int32_t e = u < a ? u : (u < a + b ? a + 2 * (u - a) : u + b);
-            const int32_t j = col[rs + e];
-            if (u >= a && u < a + b && col[rs + e + 1] != j + 1) atomicOr(flag, 2);   // an edge column without its partner
-            bcol[b0 + u] = j;
-        }
-    }
-}
-
-}  // namespace
-
-int build_block_index(Arena &ar, hipStream_t s, int64_t n, int64_t nnz, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr,
-                      const int32_t *col, BlockIndex &out, std::string &err) {
-    out = BlockIndex{};
-    if (!(pair_end > pair_begin) || n <= 0) return REMO_OK;
-    int4 *meta = ar.lo<int4>(size_t(n) + 1);
-    int32_t *bs = ar.lo<int32_t>(size_t(n) + 2);
-    int32_t *bcol = ar.lo<int32_t>(size_t(nnz) + 2);     // upper bound; the tail stays unused
-    int32_t *flag = ar.lo<int32_t>(4);
-    const size_t mark = ar.hi_mark();
-    int32_t *cnt = ar.hi<int32_t>(size_t(n) + 2), *ab = ar.hi<int32_t>(size_t(n) + 2);
-    HIP_OK(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_blk_count, dim3(grid_for(n + 1)), dim3(256), 0, s, n, pair_begin, pair_end, rowptr, col, cnt, ab);
-    {
-        size_t tb = 0;
-        HIP_OK(rocprim::exclusive_scan(nullptr, tb, cnt, bs, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s));
-        void *tmp = ar.hi<char>(tb + 256);
-        HIP_OK(rocprim::exclusive_scan(tmp, tb, cnt, bs, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s));
-    }
-    int64_t g = (n + 3) / 4;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_blk_fill, dim3(int(g)), dim3(256), 0, s, n, pair_begin, pair_end, rowptr, col, bs, ab, meta, bcol, flag);
-    int32_t h[2] = {0, 0};
-    HIP_OK(hipMemcpyAsync(&h[0], flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipMemcpyAsync(&h[1], bs + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));   // the scratch (cnt, ab, scan space) is released below
-    ar.hi_release(mark);
-    if (h[0] != 0) return REMO_OK;     // leaves out.meta == nullptr: plain CSR indices
-    out.meta = meta; out.bcol = bcol; out.units = h[1];
-    return REMO_OK;
-}
-
 }  // namespace remo

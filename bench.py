@@ -423,12 +423,29 @@ def main():
                per_rank=dict(busy_ms_per_step=[b[0] for b in busy_ranks], batches_last_step=[int(b[1]) for b in busy_ranks]))
     if args.tune:
         out["config"]["debug_tune"] = list(args.tune)
+    # assembly against ITS roofline (8 nnz values written once + 4 nnz column reads + T (4 (dim + 1) + 4) + 8 dim nv bytes)
+    if agg["batches"] and agg["ms_assemble"] > 0:
+        m0 = work[0]["mesh"]
+        asm_bytes = 12.0 * agg["nnz"] + m0.n_elems * (4 * 4 + 4) + 8.0 * 3 * m0.n_nodes
+        us = 1e3 * agg["ms_assemble"] / agg["batches"]
+        out["assembly"] = dict(kernels="k_metric_terms + k_assemble (HIP events around both)", algorithmic_bytes_per_batch=asm_bytes, us_per_batch=us,
+                               achieved_GBs=asm_bytes / us / 1e3, frac_of_hbm_peak=asm_bytes / us / 1e3 / HBM_PEAK_GBS)
 
     if extras:
         # the same sweep with the per-batch host -> device copy of the mesh arrays INSIDE the timed span (SURVEY 8d's span; the
         # one-shot entry remo_solve_batch: create + run + fetch + destroy per batch)
         dth, slab_h, agg_h, _ = timed(runner, max(1, min(args.steps, 2)), 1, sync, h2d_inclusive=True)
         log("H2D-inclusive leg done: %.3f s" % dth)
+        # two contexts on the GPU (HIP streams + arenas, one host thread each, batches dealt alternately): what Model does with
+        # gpu_workers = 2.  The launch-latency-bound quarter of one batch's PCG step is filled by the other batch's kernels; the
+        # per-kernel figures above are NOT taken from this leg (kernels that share the chip are not timed in isolation).
+        r_two = Runner(work, n_depths, local, solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps),
+                       streams=2)
+        dt2c, slab_2c, _, _ = timed(r_two, max(1, min(args.steps, 2)), 1, sync)
+        r_two.close()
+        out["value_two_contexts"] = dict(value=n_points * max(1, min(args.steps, 2)) / dt2c, unit="points/s",
+                                         max_abs_log_diff_vs_one_context=float(np.nanmax(np.abs(slab_2c - slab))))
+        log("two-context leg done: %.3f s" % dt2c)
         out["value_h2d_inclusive"] = dict(value=n_points * max(1, min(args.steps, 2)) / dth, unit="points/s",
                                           note="remo_solve_batch per batch: upload of the mesh arrays (pageable host memory) + run + fetch inside the timed span",
                                           max_abs_log_diff_vs_resident=float(np.nanmax(np.abs(slab_h - slab))))

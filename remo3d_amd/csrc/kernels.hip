@@ -240,6 +240,7 @@ void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_
 // column.  No atomics, every value written exactly once (coalesced), bit-reproducible.
 // Reference tensors are staged in LDS (19.2 KB in 3D, 7.2 KB in 2D).
 
+constexpr int kAsmRow = 448;   // stored entries of a row handled through LDS in k_assemble (longer rows: lane-per-entry walk)
 template <int DIM, bool CONDENSE>
 __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ adjptr,
@@ -251,7 +252,16 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
     __shared__ double M[NT * N * N];
     for (int i = threadIdx.x; i < NT * N * N; i += blockDim.x) M[i] = Mg[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Rows of up to kAsmRow stored entries (all but pathological vertex rows): the row's columns and two accumulators
+    // per stored entry live in LDS.  For every incident element, lane q < NK takes the element's local dof q: it finds
+    // the position of that column in the row by binary search in LDS (the 20-compare search per stored entry AND element
+    // of the first version was the cost of the kernel: 508 us per batch at 63 k tetrahedra, 5 % of the HBM roofline),
+    // forms K_e[li][q] and adds it at that position.  The positions of one element are distinct and the elements are
+    // walked in ascending order by the whole wave, so every stored entry still sums its contributions in the same
+    // fixed order: bit-identical to the lane-per-entry walk, which remains for longer rows.
+    __shared__ int32_t colL[4][kAsmRow];
+    __shared__ double accL[4][kAsmRow];      // single rows: entry p at [p]; edge-row pairs: entry p of the two rows at [2p], [2p + 1]
     // workgroups are persistent over rows: the reference tensors are staged in LDS once per workgroup, not once per 4 rows
     for (int64_t row = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nfree; row += int64_t(gridDim.x) * (blockDim.x >> 6)) {
     // the two dofs of an edge (rows r, r + 1 of the pair range) meet the same elements with local numbers li, li + 1 and
@@ -260,6 +270,59 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
     if (in_pairs && ((row - pair_begin) & 1)) continue;
     const int32_t rs = rowptr[row], re = rowptr[row + 1];
     const int32_t as = adjptr[row], ae = adjptr[row + 1];
+    if (re - rs <= (in_pairs ? kAsmRow / 2 : kAsmRow)) {
+        const int32_t len = re - rs;
+        int32_t *cl = colL[wave];
+        double *aa = accL[wave];
+        const int sh = in_pairs ? 1 : 0;
+        for (int32_t p = lane; p < len; p += 64) cl[p] = col[rs + p];
+        for (int32_t p = lane; p < (len << sh); p += 64) aa[p] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t a = as; a < ae; ++a) {
+            const uint32_t code = adj[a];  // wave-uniform
+            const int64_t t = code >> 5;
+            const int li = int(code & 31u);
+            if (lane < NK) {
+                const int32_t j = eldof[t * N + lane];
+                if (j >= 0) {
+                    int32_t lo = 0, hi = len;
+                    while (lo < hi) {                  // columns ascend; j is one of them
+                        const int32_t mid = (lo + hi) >> 1;
+                        if (cl[mid] < j) lo = mid + 1; else hi = mid;
+                    }
+                    const double *c = C + t * NT;
+                    double k = kentry<DIM>(c, M, li, lane);
+                    double k2 = in_pairs ? kentry<DIM>(c, M, li + 1, lane) : 0.0;
+                    if (CONDENSE) {  // Schur complement of the cell bubble (condense=True, ngsolve_functions.py:31)
+                        const double kbj = kentry<DIM>(c, M, 9, lane), kbb = kentry<DIM>(c, M, 9, 9);
+                        k -= kentry<DIM>(c, M, li, 9) * kbj / kbb;
+                        if (in_pairs) k2 -= kentry<DIM>(c, M, li + 1, 9) * kbj / kbb;
+                    }
+                    aa[lo << sh] += k;
+                    if (in_pairs) aa[2 * lo + 1] += k2;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int32_t p = lane; p < len; p += 64) {
+            const int32_t j = cl[p];
+            const double acc = aa[p << sh], acc2 = in_pairs ? aa[2 * p + 1] : 0.0;
+            if (in_pairs) {   // interleaved values of the pair (value_pos)
+                val[int64_t(rs) + 2 * p] = acc;
+                val[int64_t(rs) + 2 * p + 1] = acc2;
+                if (j == row) dinv[row] = 1.0 / acc;
+                if (j == row + 1) dinv[row + 1] = 1.0 / acc2;
+            } else {
+                val[rs + p] = acc;
+                if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        continue;
+    }
     for (int32_t base = rs; base < re; base += 64) {
         const int32_t p = base + lane;
         const int32_t j = (p < re) ? col[p] : -2;

@@ -279,32 +279,46 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
         for (int32_t p = lane; p < (len << sh); p += 64) aa[p] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int32_t a = as; a < ae; ++a) {
-            const uint32_t code = adj[a];  // wave-uniform
-            const int64_t t = code >> 5;
-            const int li = int(code & 31u);
-            if (lane < NK) {
-                const int32_t j = eldof[t * N + lane];
+        // NG incident elements per trip, one group of NK lanes each: the dependent chain of a trip (element's dofs -> position
+        // in the row by binary search -> element matrix entries) is latency, so the groups run it side by side; only the adds
+        // into the accumulators are taken group by group, in element order (two elements of a trip can hit the same entry).
+        constexpr int NG = 64 / NK;
+        const int grp = lane / NK, q = lane - grp * NK;
+        for (int32_t a = as; a < ae; a += NG) {
+            const bool have = grp < NG && a + grp < ae;
+            int32_t pos = -1;
+            double k = 0.0, k2 = 0.0;
+            if (have) {
+                const uint32_t code = adj[a + grp];
+                const int64_t t = code >> 5;
+                const int li = int(code & 31u);
+                const int32_t j = eldof[t * N + q];
                 if (j >= 0) {
                     int32_t lo = 0, hi = len;
                     while (lo < hi) {                  // columns ascend; j is one of them
                         const int32_t mid = (lo + hi) >> 1;
                         if (cl[mid] < j) lo = mid + 1; else hi = mid;
                     }
+                    pos = lo;
                     const double *c = C + t * NT;
-                    double k = kentry<DIM>(c, M, li, lane);
-                    double k2 = in_pairs ? kentry<DIM>(c, M, li + 1, lane) : 0.0;
+                    k = kentry<DIM>(c, M, li, q);
+                    if (in_pairs) k2 = kentry<DIM>(c, M, li + 1, q);
                     if (CONDENSE) {  // Schur complement of the cell bubble (condense=True, ngsolve_functions.py:31)
-                        const double kbj = kentry<DIM>(c, M, 9, lane), kbb = kentry<DIM>(c, M, 9, 9);
+                        const double kbj = kentry<DIM>(c, M, 9, q), kbb = kentry<DIM>(c, M, 9, 9);
                         k -= kentry<DIM>(c, M, li, 9) * kbj / kbb;
                         if (in_pairs) k2 -= kentry<DIM>(c, M, li + 1, 9) * kbj / kbb;
                     }
-                    aa[lo << sh] += k;
-                    if (in_pairs) aa[2 * lo + 1] += k2;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+                if (grp == gg && pos >= 0) {
+                    aa[pos << sh] += k;
+                    if (in_pairs) aa[2 * pos + 1] += k2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         for (int32_t p = lane; p < len; p += 64) {
             const int32_t j = cl[p];

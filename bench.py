@@ -351,7 +351,10 @@ def main():
 
     # ---- synthetic meshes: CPU-only worker processes, before this process loads the HIP library ----
     mesh_pool = None
-    if args.mesh_workers > 1 and world == 1:
+    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB"))
+    if profiled:
+        log("running under a profiler: meshes are built in this process (no child processes behind a preloaded tool library)")
+    if args.mesh_workers > 1 and world == 1 and not profiled:
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
         mesh_pool = ProcessPoolExecutor(max_workers=args.mesh_workers, mp_context=multiprocessing.get_context("spawn"))

@@ -241,11 +241,6 @@ void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_
 // Reference tensors are staged in LDS (19.2 KB in 3D, 7.2 KB in 2D).
 
 constexpr int kAsmRow = 448;   // stored entries of a row handled through LDS in k_assemble (longer rows: lane-per-entry walk)
-// Orders this wave's LDS traffic (one lane's write, another lane's later read): the LDS serves a wave's instructions in issue
-// order, so all that is needed is that the compiler neither reorders across this point nor leaves an LDS write pending in a
-// register.  A wavefront-scope fence would also wait for every outstanding GLOBAL load, i.e. for the prefetched next trip.
-__device__ __forceinline__ void lds_order() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 template <int DIM, bool CONDENSE>
 __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col, const int32_t *__restrict__ adjptr,
@@ -282,7 +277,7 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
         const int sh = in_pairs ? 1 : 0;
         for (int32_t p = lane; p < len; p += 64) cl[p] = col[rs + p];
         for (int32_t p = lane; p < (len << sh); p += 64) aa[p] = 0.0;
-        lds_order();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // NG incident elements per trip, one group of NK lanes each: the dependent chain of a trip (element's dofs -> position
         // in the row by binary search -> element matrix entries) is latency, so the groups run it side by side; only the adds
@@ -339,7 +334,7 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
                         aa[pos << sh] += k;
                         if (in_pairs) aa[2 * pos + 1] += k2;
                     }
-                    lds_order();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
                 cur = nxt;
@@ -358,7 +353,7 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
                 if (j == row) dinv[row] = 1.0 / acc;  // Jacobi = Preconditioner(a, "local"), ngsolve_functions.py:46
             }
         }
-        lds_order();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         continue;
     }

@@ -284,60 +284,40 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
         // into the accumulators are taken group by group, in element order (two elements of a trip can hit the same entry).
         constexpr int NG = 64 / NK;
         const int grp = lane / NK, q = lane - grp * NK;
-        // ... and the loads of the NEXT trip (the elements' dof numbers and metric terms: two dependent global round trips with
-        // the adjacency codes) are requested before the current trip is worked on: the codes of up to 64 incident elements
-        // are fetched at once and handed out by lane permutes.
-        for (int32_t a0 = as; a0 < ae; a0 += 64) {
-            const int32_t na = (ae - a0 < 64) ? (ae - a0) : 64;
-            const uint32_t codes = (lane < na) ? adj[a0 + lane] : 0u;
-            struct Trip { bool have; int li; int32_t j; double c[NT]; };
-            auto fetch = [&](int32_t rel) {
-                Trip tr;
-                tr.have = grp < NG && rel + grp < na;
-                const uint32_t code = uint32_t(__shfl(int(codes), tr.have ? rel + grp : 0, 64));
+        for (int32_t a = as; a < ae; a += NG) {
+            const bool have = grp < NG && a + grp < ae;
+            int32_t pos = -1;
+            double k = 0.0, k2 = 0.0;
+            if (have) {
+                const uint32_t code = adj[a + grp];
                 const int64_t t = code >> 5;
-                tr.li = int(code & 31u);
-                tr.j = -1;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) tr.c[i] = 0.0;
-                if (tr.have) {
-                    tr.j = eldof[t * N + q];
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) tr.c[i] = C[t * NT + i];
-                }
-                return tr;
-            };
-            Trip cur = fetch(0);
-            for (int32_t rel = 0; rel < na; rel += NG) {
-                const Trip nxt = fetch(rel + NG);     // rel + NG >= na: nothing is loaded
-                int32_t pos = -1;
-                double k = 0.0, k2 = 0.0;
-                if (cur.have && cur.j >= 0) {
+                const int li = int(code & 31u);
+                const int32_t j = eldof[t * N + q];
+                if (j >= 0) {
                     int32_t lo = 0, hi = len;
                     while (lo < hi) {                  // columns ascend; j is one of them
                         const int32_t mid = (lo + hi) >> 1;
-                        if (cl[mid] < cur.j) lo = mid + 1; else hi = mid;
+                        if (cl[mid] < j) lo = mid + 1; else hi = mid;
                     }
                     pos = lo;
-                    const double *c = cur.c;
-                    k = kentry<DIM>(c, M, cur.li, q);
-                    if (in_pairs) k2 = kentry<DIM>(c, M, cur.li + 1, q);
+                    const double *c = C + t * NT;
+                    k = kentry<DIM>(c, M, li, q);
+                    if (in_pairs) k2 = kentry<DIM>(c, M, li + 1, q);
                     if (CONDENSE) {  // Schur complement of the cell bubble (condense=True, ngsolve_functions.py:31)
                         const double kbj = kentry<DIM>(c, M, 9, q), kbb = kentry<DIM>(c, M, 9, 9);
-                        k -= kentry<DIM>(c, M, cur.li, 9) * kbj / kbb;
-                        if (in_pairs) k2 -= kentry<DIM>(c, M, cur.li + 1, 9) * kbj / kbb;
+                        k -= kentry<DIM>(c, M, li, 9) * kbj / kbb;
+                        if (in_pairs) k2 -= kentry<DIM>(c, M, li + 1, 9) * kbj / kbb;
                     }
                 }
+            }
 #pragma unroll
-                for (int gg = 0; gg < NG; ++gg) {
-                    if (grp == gg && pos >= 0) {
-                        aa[pos << sh] += k;
-                        if (in_pairs) aa[2 * pos + 1] += k2;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+            for (int gg = 0; gg < NG; ++gg) {
+                if (grp == gg && pos >= 0) {
+                    aa[pos << sh] += k;
+                    if (in_pairs) aa[2 * pos + 1] += k2;
                 }
-                cur = nxt;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
         for (int32_t p = lane; p < len; p += 64) {
@@ -402,7 +382,7 @@ void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, 
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s) {
     int64_t g64 = (nfree + 3) / 4;
-    if (g64 > 768) g64 = 768;   // three workgroups per CU are resident (40 KB of LDS each): the reference tensors are staged once per workgroup
+    if (g64 > 4096) g64 = 4096;
     const int grid = int(g64 < 1 ? 1 : g64);
     if (dim == 3)
         hipLaunchKernelGGL((k_assemble<3, false>), dim3(grid), dim3(256), 0, s, nfree, pair_begin, pair_end, rowptr, col, adjptr, adj, eldof, C, M, val, dinv);

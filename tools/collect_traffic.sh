@@ -2,7 +2,7 @@
 # FETCH_SIZE / WRITE_SIZE / read-request-size passes of the default bench workload (one counter per pass, kernel trace only),
 # condensed on the box by tools/pmc_traffic.py.  usage (GPU box, repo root): bash tools/collect_traffic.sh OUT_JSON
 set -e
-OUT=$1
+OUT=$(realpath -m $1)
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 ( while true; do sleep 45; echo "heartbeat $(date +%T)"; done ) &

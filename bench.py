@@ -306,6 +306,9 @@ def main():
                          "conforming revolved meshes Model uses by default for dipping models")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
+    ap.add_argument("--op", default="csr", choices=["csr", "element"],
+                    help="how the CG applies A: csr = SpMM on the assembled matrix (the headline configuration: the metric's SpMV); element = "
+                         "element-wise operator through the factorised reference tensors (remo_opts_t.op = 1)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
                          "1 = the headline configuration (per-launch SpMM timing is only meaningful without overlap)")
@@ -339,7 +342,7 @@ def main():
     import numpy as np
     strong = args.total_depths > 0
     dynamic = args.schedule == "dynamic" and world > 1
-    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune
+    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune and args.op == "csr"
     extra_specs = []
     if extras and args.sizes:
         for spec in args.sizes.split(","):
@@ -383,7 +386,7 @@ def main():
     stride = max(1, args.event_stride)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                             time_kernels=0 if args.no_events else stride, precision=args.precision,
-                            serialize_solves=(args.streams > 1 and args.overlap == "prepare"))
+                            serialize_solves=(args.streams > 1 and args.overlap == "prepare"), op=args.op)
     work = wl["work"]
     n_depths = len(wl["depths"])
     runner = Runner(work, n_depths, local, opts, streams=args.streams, schedule=args.schedule, all_resident=dynamic)
@@ -416,7 +419,7 @@ def main():
                config=dict(workload=workload_name, schedule=args.schedule if world > 1 else "single rank",
                            batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
                            points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams,
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator=args.op,
                            preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
                            max_pcg_iterations=int(agg["max_it"]), batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline_of(agg, args.precision, stride, workload_name),

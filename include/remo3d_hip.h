@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 2
+#define REMO_ABI_VERSION 3
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -73,6 +73,10 @@ typedef struct {
     int32_t serialize_solves; /* 1: the solve phase of remo_batch_run (PCG + evaluation) takes a process-wide lock, so that with
                                several contexts driven by several host threads only ONE batch is in its PCG at any time while the
                                others number / assemble theirs beside it (software pipelining across batches); 0: no lock      */
+    int32_t op;             /* how the CG applies A (CGSolver's a.mat, ngsolve_functions.py:50-51): 0 = CSR SpMM on the assembled matrix;
+                               1 = element-wise (3D only; 2D keeps 0): every tetrahedron applies its own K_e through the factorised
+                               reference tensors and the rows sum their elements' results - same operator, no stored entries read.
+                               The matrix is still assembled (Jacobi diagonal, P1 block of the preconditioner, inspection hooks) */
 } remo_opts_t;
 
 typedef struct {
@@ -172,6 +176,9 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const doubl
  */
 int remo_host_element_matrix(int32_t dim, const double *vertex_coords /*[(dim+1)*dim], sorted vertices*/,
                              double sigma, double *K_out);
+/* max |sum_m B_a[m][i] B_b[m][j] - M_ab[i][j]|: how well the factorised reference tensors of the element-wise operator
+ * (remo_opts_t.op = 1) reproduce the tensors the CSR assembly contracts (both exact polynomial integrals). */
+double remo_host_factor_error(void);
 int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes /*[6]: n_dof,n_free,nnz,n_edges,n_faces,nld*/,
                        int32_t *rowptr /*[n_free+1] or NULL*/, int32_t *col /*[nnz] or NULL*/,
                        int32_t *freeid /*[n_dof] or NULL*/);

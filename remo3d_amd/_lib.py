@@ -25,7 +25,7 @@ class RemoOpts(C.Structure):
     _fields_ = [("preconditioner", C.c_int32), ("condense", C.c_int32), ("maxsteps", C.c_int32),
                 ("check_every", C.c_int32), ("rtol", C.c_double), ("time_kernels", C.c_int32),
                 ("coarse_degree", C.c_int32), ("coarse_ratio", C.c_int32), ("precision", C.c_int32), ("inner_digits", C.c_int32),
-                ("serialize_solves", C.c_int32)]
+                ("serialize_solves", C.c_int32), ("op", C.c_int32)]
 
 
 class RemoStats(C.Structure):
@@ -48,7 +48,7 @@ class RemoStats(C.Structure):
 
 EXPORTS = ["remo_abi_version", "remo_opts_default", "remo_ctx_create", "remo_ctx_destroy", "remo_last_error",
            "remo_solve_batch", "remo_batch_create", "remo_batch_run", "remo_batch_fetch", "remo_batch_destroy",
-           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_symbolic", "remo_debug_tune"]
+           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic", "remo_debug_tune"]
 
 _lib = None
 
@@ -91,6 +91,7 @@ def load():
     L.remo_batch_spmv.argtypes = [vp, vp, C.c_int32, dp, dp, C.c_int32, dp]
     L.remo_host_element_matrix.restype = C.c_int
     L.remo_host_element_matrix.argtypes = [C.c_int32, dp, C.c_double, dp]
+    L.remo_host_factor_error.restype = C.c_double
     L.remo_host_symbolic.restype = C.c_int
     L.remo_host_symbolic.argtypes = [C.POINTER(RemoMesh), C.c_int32, i64p, ip, ip, ip]
     L.remo_debug_tune.argtypes = [C.c_int32, C.c_int32]

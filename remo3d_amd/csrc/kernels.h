@@ -46,6 +46,16 @@ template <class T> struct PcgBuffersT {
 using PcgBuffers = PcgBuffersT<double>;
 constexpr int kScalarSlots = 48;   // doubles behind PcgBuffersT::rz0
 
+// Element-wise operator (3D, remo_opts_t.op = 1): everything y = A x needs instead of the stored matrix
+template <class T> struct ElemOpT {
+    int64_t nt = 0;
+    const int32_t *eldof = nullptr;   // [nt][20] free row of every local dof or -1
+    const double *C = nullptr;        // [nt][6] metric terms (launch_metric_terms)
+    const int32_t *adjptr = nullptr;  // [n + 1] row -> incident (element, local dof) codes, ascending
+    const uint32_t *adj = nullptr;    // element << 5 | local dof
+    T *Ye = nullptr;                  // [nt][20][k] scratch slab of the element results
+};
+
 template <class T> struct CsrViewT {
     int64_t n;
     int64_t nnz;
@@ -55,6 +65,7 @@ template <class T> struct CsrViewT {
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
     // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
+    const ElemOpT<T> *elem = nullptr;   // != nullptr: launch_spmm applies the element-wise operator instead of the stored entries
 };
 using CsrView = CsrViewT<double>;
 

@@ -107,6 +107,8 @@ struct remo_batch {
     double *d_val = nullptr, *d_dinv = nullptr;
     double *d_x = nullptr, *d_C = nullptr;  // solution block [n][k_last] and metric terms of the last run
     double *d_f = nullptr;                  // load vectors [n][k_last] of the last chunk
+    ElemOpT<double> elem64{};               // element-wise operator of the last run (remo_opts_t.op = 1), pointers into the arena
+    ElemOpT<float> elem32{};
     int k_last = 0;
     uint64_t run_id = 0;
     std::vector<double> u_out;
@@ -502,6 +504,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
+        if (o.op == 1 && dim == 3) need += size_t(nt) * 20 * size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4096;   // element result slab(s)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -648,6 +651,11 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
+        const bool elem_op = (o.op == 1 && dim == 3);
+        if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
+            b->elem64 = ElemOpT<double>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, ctx->take<double>(size_t(nt) * 20 * size_t(kmax))};
+            b->A.elem = &b->elem64;
+        }
         b->d_val = d_val;
         b->d_dinv = d_dinv;
         b->d_x = buf.x;
@@ -672,6 +680,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             launch_to_float(n, d_dinv, dinv32, s);
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
+            if (elem_op) {
+                b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
+                mx.A32.elem = &b->elem32;
+            }
             PcgBuffersT<float> &f = mx.b32;
             f.x = ctx->take<float>(size_t(n) * kmax); f.r = ctx->take<float>(size_t(n) * kmax);
             f.p = ctx->take<float>(size_t(n) * kmax + 4); f.q = ctx->take<float>(size_t(n) * kmax);
@@ -935,6 +947,8 @@ int remo_host_element_matrix(int32_t dim, const double *X, double sigma, double 
     }
     return REMO_OK;
 }
+
+double remo_host_factor_error(void) { return ref_factors3_error(); }
 
 int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes, int32_t *rowptr, int32_t *col, int32_t *freeid) {
     if (!mesh || !sizes) return REMO_ERR_ARG;

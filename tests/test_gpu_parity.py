@@ -443,3 +443,65 @@ def test_compact_vertex_block_is_the_same_operator(precision, mesh3d, gpu_ctx):
     finally:
         L.remo_debug_tune(9, 1); L.remo_debug_tune(13, 1)
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_element_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
+    """remo_opts_t.op = 1 (3D): y = A x element by element through the factorised reference tensors equals the CSR product and
+    the oracle's (different arithmetic routes: quadrature / contracted tensors / factorised tensors; Dirichlet rows eliminated
+    the same way)."""
+    from remo3d_amd import _lib, solver
+    from oracle.fem_oracle import Oracle
+    assert _lib.load().remo_host_factor_error() < 1e-14
+    o = Oracle(mesh3d, SIGMA3, condense=True)
+    x = np.random.default_rng(k).standard_normal((o.nfree, k))
+    xx = x if k > 1 else x[:, 0]
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1])
+    try:
+        ys = {}
+        for op in ("csr", "element"):
+            b.run(solver.make_opts(preconditioner="local", rtol=1e-2, op=op))
+            ys[op], _ = b.spmv(xx, reps=2)
+        yr = np.stack([o.spmv(x[:, c]) for c in range(k)], 1).reshape(ys["csr"].shape)
+        scale = np.max(np.abs(yr))
+        assert np.max(np.abs(ys["element"] - yr)) <= 5e-12 * scale
+        assert np.max(np.abs(ys["element"] - ys["csr"])) <= 5e-12 * scale
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+@pytest.mark.parametrize("pre", ["local", "multigrid"])
+def test_element_operator_solves_like_the_csr_path(precision, pre, mesh3d, gpu_ctx):
+    """The same PCG on the element-wise operator: potentials of the CSR path and of the oracle, similar step counts, 9 right-hand
+    sides (chunks of 8 + 1); 2D batches ignore the option."""
+    from remo3d_amd import solver
+    o, ref = _oracle_solve(mesh3d, SIGMA3, True)
+    res = {}
+    for op in ("csr", "element"):
+        outs, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-12, maxsteps=20000, precision=precision, op=op))
+        assert rc == 0
+        res[op] = (outs, max(st["iterations"][:3]))
+        for g, r in zip(outs, ref):
+            assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
+    assert abs(res["csr"][1] - res["element"][1]) <= max(3, res["csr"][1] // 20), (res["csr"][1], res["element"][1])
+    zs = np.linspace(-0.4, 0.4, 9)
+    src = [([z], [1.0]) for z in zs]
+    ev = [[z + 0.4, z + 6.4] for z in zs]
+    a, _, rca = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="element", maxsteps=5000))
+    c, _, rcc = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="csr", maxsteps=5000))
+    assert rca == 0 and rcc == 0
+    for u, v in zip(a, c):
+        assert np.allclose(u, v, rtol=1e-8, atol=0)
+
+
+@pytest.mark.gpu
+def test_element_operator_is_ignored_in_2d(mesh2d, gpu_ctx):
+    from remo3d_amd import solver
+    a, _, rca = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="element"))
+    c, _, rcc = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="csr"))
+    assert rca == 0 and rcc == 0
+    for u, v in zip(a, c):
+        assert np.array_equal(u, v)

@@ -53,8 +53,11 @@ template <class T> struct ElemOpT {
     const double *C = nullptr;        // [nt][6] metric terms (launch_metric_terms)
     const int32_t *adjptr = nullptr;  // [n + 1] row -> incident (element, local dof) codes, ascending
     const uint32_t *adj = nullptr;    // element << 5 | local dof
-    T *Ye = nullptr;                  // [nt][20][k] scratch slab of the element results
+    const int32_t *slot = nullptr;    // [nt][20] position of (element, local dof) in the adjacency list, -1 = constrained (launch_elem_slots)
+    int64_t nadj = 0;                 // upper bound of the adjacency entries (nt * 20): rows of the slab
+    T *Ye = nullptr;                  // [nadj][k] scratch slab: an element's result rows at their adjacency positions
 };
+void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s);
 
 template <class T> struct CsrViewT {
     int64_t n;

@@ -640,80 +640,159 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 // of 2.6 kB of matrix: the work moves from the vector-memory path, which bounds the CSR kernel, to the fp64 pipes.
 #include "build/elem_apply.inc"
 
-template <class T, int K>
-__global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, const int32_t *__restrict__ eldof, const double *__restrict__ C,
-                                                    const T *__restrict__ x, T *__restrict__ Ye, const double *__restrict__ scal, int step) {
-    if (scal && solve_done(scal, step)) return;
-    constexpr int LE = 64 / K;                      // elements per wave: lane = (element slot, right-hand side)
-    const int lane = threadIdx.x & 63;
-    const int es = lane / K, c = lane - es * K;
-    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    if (es >= LE) return;
-    for (int64_t e = wave * LE + es; e < nt; e += nwaves * LE) {
-        const int32_t *ed = eldof + e * 20;
-        T xv[20];
+// ---- buffer accesses with the hardware range check: a lane with nothing to load / store hands the instruction an offset
+// beyond the descriptor's range - the load returns 0, the store is dropped, and neither sends a request down the
+// vector-memory path.  No branch around the access, so the compiler keeps all of them in flight together.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t kOutOfRange = 0xFFFFF000u;   // beyond any descriptor the launcher accepts
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, int(uint32_t(bytes)), 0x00020000);
+}
+template <class T, int N> __device__ __forceinline__ void buf_load(rsrc_t r, uint32_t off, T (&out)[N]) {   // N values from byte offset off (multiple of 4)
+    constexpr int W = N * int(sizeof(T)) / 4;
+    unsigned int w[W];
+    int d = 0;
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const int32_t r = ed[i];
-            xv[i] = r >= 0 ? x[int64_t(r) * K + c] : T(0);          // constrained dofs carry u = 0
+    for (; d + 4 <= W; d += 4) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, off + 4u * d, 0, 0);
+        w[d] = q.x; w[d + 1] = q.y; w[d + 2] = q.z; w[d + 3] = q.w;
+    }
+    if constexpr ((W & 3) >= 2) {
+        const u32x2_t q = __builtin_amdgcn_raw_buffer_load_b64(r, off + 4u * (W & ~3), 0, 0);
+        w[W & ~3] = q.x; w[(W & ~3) + 1] = q.y;
+    }
+    if constexpr (W & 1) w[W - 1] = __builtin_amdgcn_raw_buffer_load_b32(r, off + 4u * (W - 1), 0, 0);
+    __builtin_memcpy(out, w, sizeof(T) * N);
+}
+template <class T, int N> __device__ __forceinline__ void buf_store(rsrc_t r, uint32_t off, const T (&in)[N]) {
+    constexpr int W = N * int(sizeof(T)) / 4;
+    unsigned int w[W];
+    __builtin_memcpy(w, in, sizeof(T) * N);
+    int d = 0;
+#pragma unroll
+    for (; d + 4 <= W; d += 4) {
+        u32x4_t q; q.x = w[d]; q.y = w[d + 1]; q.z = w[d + 2]; q.w = w[d + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(q, r, off + 4u * d, 0, 0);
+    }
+    if constexpr ((W & 3) >= 2) {
+        u32x2_t q; q.x = w[W & ~3]; q.y = w[(W & ~3) + 1];
+        __builtin_amdgcn_raw_buffer_store_b64(q, r, off + 4u * (W & ~3), 0, 0);
+    }
+    if constexpr (W & 1) __builtin_amdgcn_raw_buffer_store_b32(w[W - 1], r, off + 4u * (W - 1), 0, 0);
+}
+
+// slot[t * 20 + li] = position of (element t, local dof li) in the row-sorted adjacency list, -1 for constrained dofs: where
+// pass 1 puts an element's result rows so that pass 2 finds the contributions of a matrix row side by side
+__global__ void __launch_bounds__(256) k_elem_slots(int64_t n, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj, int32_t *__restrict__ slot) {
+    const int64_t total = adjptr[n];
+    for (int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; a < total; a += int64_t(gridDim.x) * blockDim.x) {
+        const uint32_t code = adj[a];
+        slot[int64_t(code >> 5) * 20 + int64_t(code & 31u)] = int32_t(a);
+    }
+}
+void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s) {
+    (void)hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * size_t(nt) * 20, s);
+    hipLaunchKernelGGL(k_elem_slots, dim3(2048), dim3(256), 0, s, n, adjptr, adj, slot);
+}
+
+// Pass 1.  One LANE per tetrahedron: the lane gathers whole rows of x (k values: 3 requests for 5 doubles, where a lane per
+// (element, right-hand side) needs 5), works the right-hand sides off one after the other - the result of a column
+// overwrites the registers of its input - and stores whole result rows at the rows' adjacency slots.
+template <class T, int K>
+__global__ void __launch_bounds__(64) k_elem_apply(int64_t nt, int64_t n, int64_t nadj, const int32_t *__restrict__ eldof, const int32_t *__restrict__ slot,
+                                                   const double *__restrict__ C, const T *__restrict__ x, T *__restrict__ Ye,
+                                                   const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
+    constexpr uint32_t S = sizeof(T);
+    const rsrc_t rx = make_rsrc(x, uint64_t(n) * K * S), ry = make_rsrc(Ye, uint64_t(nadj) * K * S);
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nt; e += int64_t(gridDim.x) * blockDim.x) {
+        int32_t ed[20], sl[20];
+        {
+            const int4 *pe = reinterpret_cast<const int4 *>(eldof + e * 20), *ps = reinterpret_cast<const int4 *>(slot + e * 20);   // 80-byte records: 16-byte aligned
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int4 a = pe[q], b = ps[q];
+                ed[4 * q] = a.x; ed[4 * q + 1] = a.y; ed[4 * q + 2] = a.z; ed[4 * q + 3] = a.w;
+                sl[4 * q] = b.x; sl[4 * q + 1] = b.y; sl[4 * q + 2] = b.z; sl[4 * q + 3] = b.w;
+            }
         }
         const double *ce = C + e * 6;                               // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
         const T c11 = T(ce[0]), c12 = T(ce[1]), c13 = T(ce[2]), c22 = T(ce[3]), c23 = T(ce[4]), c33 = T(ce[5]);
-        T g[30], h[30], y[20];
-        REMO_ELEM_GRAD(T, xv, g)
+        T xy[20][K];
 #pragma unroll
-        for (int m = 0; m < 10; ++m) {
-            h[m] = c11 * g[m] + c12 * g[10 + m] + c13 * g[20 + m];
-            h[10 + m] = c12 * g[m] + c22 * g[10 + m] + c23 * g[20 + m];
-            h[20 + m] = c13 * g[m] + c23 * g[10 + m] + c33 * g[20 + m];
+        for (int i = 0; i < 20; ++i) buf_load<T, K>(rx, ed[i] >= 0 ? uint32_t(ed[i]) * (K * S) : kOutOfRange, xy[i]);   // constrained dofs carry u = 0
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            T xv[20], g[30], h[30], y[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) xv[i] = xy[i][c];
+            REMO_ELEM_GRAD(T, xv, g)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                h[m] = c11 * g[m] + c12 * g[10 + m] + c13 * g[20 + m];
+                h[10 + m] = c12 * g[m] + c22 * g[10 + m] + c23 * g[20 + m];
+                h[20 + m] = c13 * g[m] + c23 * g[10 + m] + c33 * g[20 + m];
+            }
+            REMO_ELEM_DIV(T, h, y)
+#pragma unroll
+            for (int i = 0; i < 20; ++i) xy[i][c] = y[i];
         }
-        REMO_ELEM_DIV(T, h, y)
-        T *out = Ye + e * (20 * K) + c;
 #pragma unroll
-        for (int i = 0; i < 20; ++i) out[i * K] = y[i];
+        for (int i = 0; i < 20; ++i) buf_store<T, K>(ry, sl[i] >= 0 ? uint32_t(sl[i]) * (K * S) : kOutOfRange, xy[i]);
     }
 }
 
+// Pass 2.  One lane per matrix row: the row's contributions are adjacent in the slab (adjacency order = ascending elements:
+// the same fixed summation order as the assembly), read as whole k-wide rows.
 template <class T, int K, bool DOT>
-__global__ void __launch_bounds__(256) k_elem_reduce(int64_t n, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
-                                                     const T *__restrict__ Ye, const T *__restrict__ x, T *__restrict__ y,
-                                                     double *__restrict__ part, const double *__restrict__ scal, int step) {
+__global__ void __launch_bounds__(256) k_elem_reduce(int64_t n, int64_t nadj, const int32_t *__restrict__ adjptr, const T *__restrict__ Ye,
+                                                     const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part,
+                                                     const double *__restrict__ scal, int step) {
     if (scal && solve_done(scal, step)) return;
-    constexpr int LE = 64 / K;                      // rows per wave: lane = (row slot, right-hand side)
-    const int lane = threadIdx.x & 63;
-    const int rsl = lane / K, c = lane - rsl * K;
-    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    double dot = 0.0;
-    if (rsl < LE)
-        for (int64_t row = wave * LE + rsl; row < n; row += nwaves * LE) {
-            const int32_t as = adjptr[row], ae = adjptr[row + 1];
-            T acc = T(0);
-            for (int32_t a = as; a < ae; ++a) {
-                const uint32_t code = adj[a];
-                acc += Ye[(int64_t(code >> 5) * 20 + int64_t(code & 31u)) * K + c];
-            }
-            y[row * K + c] = acc;
-            if (DOT) dot += double(acc) * double(x[row * K + c]);
+    constexpr uint32_t S = sizeof(T);
+    const rsrc_t rs = make_rsrc(Ye, uint64_t(nadj) * K * S), rxx = make_rsrc(x, uint64_t(n) * K * S), ryy = make_rsrc(y, uint64_t(n) * K * S);
+    double dot[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    for (int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += int64_t(gridDim.x) * blockDim.x) {
+        const int32_t as = adjptr[row], ae = adjptr[row + 1];
+        T acc[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[c] = T(0);
+        for (int32_t a = as; a < ae; a += 4) {          // four slab rows in flight (rows past the end: out of range, zero, no request)
+            T v[4][K];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) buf_load<T, K>(rs, a + u < ae ? uint32_t(a + u) * (K * S) : kOutOfRange, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < K; ++c) acc[c] += v[u][c];
         }
+        buf_store<T, K>(ryy, uint32_t(row) * (K * S), acc);
+        if (DOT) {
+            T xr[K];
+            buf_load<T, K>(rxx, uint32_t(row) * (K * S), xr);
+#pragma unroll
+            for (int c = 0; c < K; ++c) dot[c] += double(acc[c]) * double(xr[c]);
+        }
+    }
     if (DOT) {
         __shared__ double smem[16 * K];
-        double dcol[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) dcol[j] = (rsl < LE && j == c) ? dot : 0.0;
-        block_sum<K>(dcol, smem);
-        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dcol, threadIdx.x);
+        block_sum<K>(dot, smem);
+        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
     }
 }
 
 template <class T, int K> static void elem_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
     const ElemOpT<T> &E = *A.elem;
-    constexpr int LE = 64 / K;
-    int64_t g1 = (E.nt + 4 * LE - 1) / (4 * LE);
-    if (g1 > 2048) g1 = 2048;
+    int64_t g1 = (E.nt + 63) / 64;
+    if (g1 > 16384) g1 = 16384;
     if (g1 < 1) g1 = 1;
-    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(256), 0, s, E.nt, E.eldof, E.C, x, E.Ye, scal, step);
-    if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.adjptr, E.adj, (const T *)E.Ye, x, y, part, scal, step);
-    else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.adjptr, E.adj, (const T *)E.Ye, x, y, part, scal, step);
+    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(64), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
+    if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
+    else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
 }
 
 // tuning knobs (remo_debug_tune): 0 = heuristic default

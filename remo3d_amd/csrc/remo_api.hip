@@ -504,7 +504,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        if (o.op == 1 && dim == 3) need += size_t(nt) * 20 * size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4096;   // element result slab(s)
+        if (o.op == 1 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;   // element result slab(s)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -653,7 +653,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
         const bool elem_op = (o.op == 1 && dim == 3);
         if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
-            b->elem64 = ElemOpT<double>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, ctx->take<double>(size_t(nt) * 20 * size_t(kmax))};
+            int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);
+            launch_elem_slots(n, nt, sy.adjptr, sy.adj, d_slot, s);
+            b->elem64 = ElemOpT<double>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, d_slot, nt * 20, ctx->take<double>(size_t(nt) * 20 * size_t(kmax))};
             b->A.elem = &b->elem64;
         }
         b->d_val = d_val;
@@ -681,7 +683,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
             if (elem_op) {
-                b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
+                b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, b->elem64.slot, nt * 20, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
                 mx.A32.elem = &b->elem32;
             }
             PcgBuffersT<float> &f = mx.b32;

@@ -316,9 +316,9 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,L:4,conforming-M:8",
-                    help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes), "
-                         "reported in the `sizes` array; '' = none")
+    ap.add_argument("--sizes", default="M:8,L:4,L/mixed/element:4,conforming-M:8",
+                    help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
+                         "'/mixed' = fp32 PCG in fp64 refinement, '/element' = element-wise operator), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -348,8 +348,8 @@ def main():
         for spec in args.sizes.split(","):
             name, nb = spec.split(":")
             conf = name.startswith("conforming-")
-            size = name.split("-")[-1]
-            if not (size == args.size and not conf):
+            size = name.split("/")[0].split("-")[-1]
+            if not (name == args.size):
                 extra_specs.append((name, size, "conforming" if conf else "lattice", int(nb)))
 
     # ---- synthetic meshes: CPU-only worker processes, before this process loads the HIP library ----
@@ -364,7 +364,12 @@ def main():
     t_mesh0 = time.time()
     wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh, total_depths=args.total_depths or None,
                         all_batches=dynamic, pool=mesh_pool)
-    extra_wl = [(name, build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)) for name, size, kind, nb in extra_specs]   # the 20-depth sweep of the same model: 8 batches
+    built = {}
+    extra_wl = []
+    for name, size, kind, nb in extra_specs:     # the 20-depth sweep of the same model: 8 batches; variants of one size share its meshes
+        if (size, kind, nb) not in built:
+            built[(size, kind, nb)] = build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)
+        extra_wl.append((name, built[(size, kind, nb)]))
     if mesh_pool is not None:
         mesh_pool.shutdown()
     mesh_wall = time.time() - t_mesh0
@@ -467,14 +472,18 @@ def main():
 
     sizes = []
     for name, w2 in extra_wl:
-        r2 = Runner(w2["work"], len(w2["depths"]), local, opts)
+        prec2 = "mixed" if "/mixed" in name else args.precision
+        op2 = "element" if "/element" in name else args.op
+        opts2 = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
+                                 time_kernels=0 if args.no_events else stride, precision=prec2, op=op2)
+        r2 = Runner(w2["work"], len(w2["depths"]), local, opts2)
         st2 = 2
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
         pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
-        rf = roofline_of(agg2, args.precision, stride)
-        sizes.append(dict(workload=name, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
+        rf = roofline_of(agg2, prec2, stride)
+        sizes.append(dict(workload=name, precision=prec2, operator=op2, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
                           n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
-                          max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"], spmm_avg_launch_us=rf["avg_launch_us"],
+                          max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"] if op2 == "csr" else None, apply_avg_launch_us=rf["avg_launch_us"],
                           solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))
         r2.close()
         log("size leg %s done: %.3f s for %d steps" % (name, dt2, st2))

@@ -697,17 +697,28 @@ void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint3
     hipLaunchKernelGGL(k_elem_slots, dim3(2048), dim3(256), 0, s, n, adjptr, adj, slot);
 }
 
-// Pass 1.  One LANE per tetrahedron: the lane gathers whole rows of x (k values: 3 requests for 5 doubles, where a lane per
-// (element, right-hand side) needs 5), works the right-hand sides off one after the other - the result of a column
-// overwrites the registers of its input - and stores whole result rows at the rows' adjacency slots.
+// Pass 1.  Lane = (tetrahedron, PAIR of right-hand sides): k = 5 takes three lanes per element, 21 elements per wave.  A
+// lane gathers 16 bytes of every x row (the three lanes of an element 16 + 16 + 8: as many requests as one 40-byte row),
+// carries both columns through the factorised tensors as 2-vectors (every constant is materialised once for two
+// multiply-adds, and the two are independent), and stores its two columns of the 20 result rows at the rows' adjacency
+// slots.  ~200 VGPRs: two waves per SIMD.  (One lane per element with all columns in registers - 256 VGPRs + 68 AGPRs,
+// one wave per SIMD - ran 15 cycles per instruction: dependent fp64 chains and SGPR spills with nothing to hide them;
+// one lane per (element, column) needs 2.6x the requests.)
 template <class T, int K>
-__global__ void __launch_bounds__(64) k_elem_apply(int64_t nt, int64_t n, int64_t nadj, const int32_t *__restrict__ eldof, const int32_t *__restrict__ slot,
-                                                   const double *__restrict__ C, const T *__restrict__ x, T *__restrict__ Ye,
-                                                   const double *__restrict__ scal, int step) {
+__global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64_t nadj, const int32_t *__restrict__ eldof, const int32_t *__restrict__ slot,
+                                                    const double *__restrict__ C, const T *__restrict__ x, T *__restrict__ Ye,
+                                                    const double *__restrict__ scal, int step) {
     if (scal && solve_done(scal, step)) return;
+    typedef T T2 __attribute__((ext_vector_type(2)));
     constexpr uint32_t S = sizeof(T);
+    constexpr int NL = (K + 1) / 2, EPW = 64 / NL;       // lanes per element, elements per wave
     const rsrc_t rx = make_rsrc(x, uint64_t(n) * K * S), ry = make_rsrc(Ye, uint64_t(nadj) * K * S);
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nt; e += int64_t(gridDim.x) * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int es = lane / NL, c0 = 2 * (lane - es * NL);
+    const bool two = c0 + 1 < K;                          // the last lane of an odd k carries one column
+    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    if (es >= EPW) return;
+    for (int64_t e = wave * EPW + es; e < nt; e += nwaves * EPW) {
         int32_t ed[20], sl[20];
         {
             const int4 *pe = reinterpret_cast<const int4 *>(eldof + e * 20), *ps = reinterpret_cast<const int4 *>(slot + e * 20);   // 80-byte records: 16-byte aligned
@@ -720,27 +731,29 @@ __global__ void __launch_bounds__(64) k_elem_apply(int64_t nt, int64_t n, int64_
         }
         const double *ce = C + e * 6;                               // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
         const T c11 = T(ce[0]), c12 = T(ce[1]), c13 = T(ce[2]), c22 = T(ce[3]), c23 = T(ce[4]), c33 = T(ce[5]);
-        T xy[20][K];
+        T2 xv[20], g[30], y[20];
 #pragma unroll
-        for (int i = 0; i < 20; ++i) buf_load<T, K>(rx, ed[i] >= 0 ? uint32_t(ed[i]) * (K * S) : kOutOfRange, xy[i]);   // constrained dofs carry u = 0
-#pragma unroll
-        for (int c = 0; c < K; ++c) {
-            T xv[20], g[30], h[30], y[20];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) xv[i] = xy[i][c];
-            REMO_ELEM_GRAD(T, xv, g)
-#pragma unroll
-            for (int m = 0; m < 10; ++m) {
-                h[m] = c11 * g[m] + c12 * g[10 + m] + c13 * g[20 + m];
-                h[10 + m] = c12 * g[m] + c22 * g[10 + m] + c23 * g[20 + m];
-                h[20 + m] = c13 * g[m] + c23 * g[10 + m] + c33 * g[20 + m];
-            }
-            REMO_ELEM_DIV(T, h, y)
-#pragma unroll
-            for (int i = 0; i < 20; ++i) xy[i][c] = y[i];
+        for (int i = 0; i < 20; ++i) {     // constrained dofs carry u = 0; a lone last column reads its right neighbour too (ignored below)
+            T w[2];
+            buf_load<T, 2>(rx, ed[i] >= 0 ? (uint32_t(ed[i]) * K + c0) * S : kOutOfRange, w);
+            xv[i].x = w[0]; xv[i].y = two ? w[1] : T(0);
         }
+        REMO_ELEM_GRAD(T2, xv, g)
 #pragma unroll
-        for (int i = 0; i < 20; ++i) buf_store<T, K>(ry, sl[i] >= 0 ? uint32_t(sl[i]) * (K * S) : kOutOfRange, xy[i]);
+        for (int m = 0; m < 10; ++m) {     // h = c~ g, in place
+            const T2 g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
+            g[m] = c11 * g1 + c12 * g2 + c13 * g3;
+            g[10 + m] = c12 * g1 + c22 * g2 + c23 * g3;
+            g[20 + m] = c13 * g1 + c23 * g2 + c33 * g3;
+        }
+        REMO_ELEM_DIV(T2, g, y)
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            const uint32_t off = sl[i] >= 0 ? (uint32_t(sl[i]) * K + c0) * S : kOutOfRange;
+            T w1[1] = {y[i].x}, w2[1] = {y[i].y};
+            buf_store<T, 1>(ry, off, w1);
+            buf_store<T, 1>(ry, two ? off + S : kOutOfRange, w2);
+        }
     }
 }
 
@@ -787,10 +800,11 @@ __global__ void __launch_bounds__(256) k_elem_reduce(int64_t n, int64_t nadj, co
 
 template <class T, int K> static void elem_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
     const ElemOpT<T> &E = *A.elem;
-    int64_t g1 = (E.nt + 63) / 64;
-    if (g1 > 16384) g1 = 16384;
+    constexpr int EPW = 64 / ((K + 1) / 2);
+    int64_t g1 = (E.nt + 4 * EPW - 1) / (4 * EPW);
+    if (g1 > 4096) g1 = 4096;
     if (g1 < 1) g1 = 1;
-    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(64), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
+    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
     if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
     else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
 }

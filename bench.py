@@ -220,13 +220,13 @@ class Runner:
         agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
         for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
             agg[k] += st[k]
-        agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]; agg["batches"] += 1
+        agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]; agg["batches"] += 1; agg["op_used"] = st["op_used"]
 
     def one_step(self, h2d_inclusive=False):
         np = self.np
         slab = np.zeros((self.n_depths, len(TOOLS)))
         agg = dict(spmv_ms=0.0, spmv_ms_raw=0.0, spmv_launches=0, spmv_bytes_total=0.0, pcg_steps=0, not_converged=0, ms_symbolic=0.0,
-                   ms_assemble=0.0, ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0, batches=0, ev_over=0.0)
+                   ms_assemble=0.0, ms_solve=0.0, ms_h2d=0.0, ms_eval=0.0, n=0, nnz=0, max_it=0, batches=0, ev_over=0.0, op_used=0)
         t_busy = time.time()
         if h2d_inclusive:     # the host-buffer entry: every batch is copied to the device inside the timed span (remo_solve_batch)
             for w in self.work:
@@ -266,7 +266,10 @@ def roofline_of(agg, precision, stride, workload_name=None):
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
     r = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
              traffic=pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"])) if (workload_name and precision == "fp64") else None)
-    r.update(kernel="k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)" % ("fp64" if precision == "fp64" else "fp32 values and vectors"),
+    elem = bool(agg.get("op_used"))
+    r.update(kernel=("k_elem_apply + k_elem_reduce (element-wise operator, %s; `achieved` prices the CSR product's algorithmic bytes at this time)" if elem
+                     else "k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)") % ("fp64" if precision == "fp64" else "fp32 values and vectors"),
+             operator="element" if elem else "csr",
              timed="every %d-th launch of every solve, HIP events on the solver's stream, over the timed steps" % stride,
              launches=int(agg["spmv_launches"]),
              avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
@@ -306,9 +309,10 @@ def main():
                          "conforming revolved meshes Model uses by default for dipping models")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
-    ap.add_argument("--op", default="csr", choices=["csr", "element"],
-                    help="how the CG applies A: csr = SpMM on the assembled matrix (the headline configuration: the metric's SpMV); element = "
-                         "element-wise operator through the factorised reference tensors (remo_opts_t.op = 1)")
+    ap.add_argument("--op", default="auto", choices=["auto", "csr", "element"],
+                    help="how the CG applies A: csr = SpMM on the assembled matrix; element = element-wise operator through the factorised "
+                         "reference tensors; auto (the library's default) = csr up to 17 M stored entries - the headline size S, whose SpMM the "
+                         "roofline object describes - element-wise above")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
                          "1 = the headline configuration (per-launch SpMM timing is only meaningful without overlap)")
@@ -316,9 +320,9 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,L:4,L/mixed/element:4,conforming-M:8",
+    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
-                         "'/mixed' = fp32 PCG in fp64 refinement, '/element' = element-wise operator), reported in the `sizes` array; '' = none")
+                         "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -342,7 +346,7 @@ def main():
     import numpy as np
     strong = args.total_depths > 0
     dynamic = args.schedule == "dynamic" and world > 1
-    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune and args.op == "csr"
+    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune and args.op == "auto"
     extra_specs = []
     if extras and args.sizes:
         for spec in args.sizes.split(","):
@@ -424,7 +428,7 @@ def main():
                config=dict(workload=workload_name, schedule=args.schedule if world > 1 else "single rank",
                            batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
                            points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator=args.op,
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator="element" if agg["op_used"] else "csr",
                            preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
                            max_pcg_iterations=int(agg["max_it"]), batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline_of(agg, args.precision, stride, workload_name),
@@ -473,7 +477,7 @@ def main():
     sizes = []
     for name, w2 in extra_wl:
         prec2 = "mixed" if "/mixed" in name else args.precision
-        op2 = "element" if "/element" in name else args.op
+        op2 = "element" if "/element" in name else ("csr" if "/csr" in name else args.op)
         opts2 = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                                  time_kernels=0 if args.no_events else stride, precision=prec2, op=op2)
         r2 = Runner(w2["work"], len(w2["depths"]), local, opts2)
@@ -481,6 +485,7 @@ def main():
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
         pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
         rf = roofline_of(agg2, prec2, stride)
+        op2 = "element" if agg2["op_used"] else "csr"
         sizes.append(dict(workload=name, precision=prec2, operator=op2, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
                           n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
                           max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"] if op2 == "csr" else None, apply_avg_launch_us=rf["avg_launch_us"],

@@ -73,10 +73,15 @@ typedef struct {
     int32_t serialize_solves; /* 1: the solve phase of remo_batch_run (PCG + evaluation) takes a process-wide lock, so that with
                                several contexts driven by several host threads only ONE batch is in its PCG at any time while the
                                others number / assemble theirs beside it (software pipelining across batches); 0: no lock      */
-    int32_t op;             /* how the CG applies A (CGSolver's a.mat, ngsolve_functions.py:50-51): 0 = CSR SpMM on the assembled matrix;
-                               1 = element-wise (3D only; 2D keeps 0): every tetrahedron applies its own K_e through the factorised
-                               reference tensors and the rows sum their elements' results - same operator, no stored entries read.
-                               The matrix is still assembled (Jacobi diagonal, P1 block of the preconditioner, inspection hooks) */
+    int32_t op;             /* how the CG applies A (CGSolver's a.mat, ngsolve_functions.py:50-51):
+                               2 = CSR SpMM on the assembled matrix;
+                               1 = element-wise (3D only; 2D always uses the CSR product): every tetrahedron applies its own K_e
+                                   through the factorised reference tensors and the rows sum their elements' results - same
+                                   operator to rounding, no stored entries read;
+                               0 = by size (default): element-wise in 3D once the matrix no longer stays in the 256 MB of
+                                   Infinity Cache between launches (more than 17 M stored entries: there the element-wise form takes
+                                   24-26 % less time than the CSR product, below it the CSR product is 20 % ahead), else CSR.
+                               The matrix is assembled either way (Jacobi diagonal, P1 block of the preconditioner, inspection hooks) */
 } remo_opts_t;
 
 typedef struct {
@@ -103,6 +108,8 @@ typedef struct {
     double event_overhead_ms; /* elapsed time of an EMPTY hipEvent pair on the stream (min of 16),
                             i.e. what a bracket measures beyond the kernel it encloses             */
     int64_t refinement_cycles; /* mixed precision: fp32 inner solves that contributed a correction (all chunks) */
+    int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 1 = element by element (remo_opts_t.op) */
+    int32_t reserved;
 } remo_stats_t;
 
 typedef struct remo_ctx remo_ctx_t;

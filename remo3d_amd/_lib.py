@@ -36,7 +36,7 @@ class RemoStats(C.Structure):
                 ("ms_solve", C.c_double), ("ms_eval", C.c_double), ("ms_total", C.c_double),
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_double),
                 ("pcg_steps", C.c_int64), ("spmv_ms_raw", C.c_double), ("event_overhead_ms", C.c_double),
-                ("refinement_cycles", C.c_int64)]
+                ("refinement_cycles", C.c_int64), ("op_used", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         d = {}

@@ -504,7 +504,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        if (o.op == 1 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;   // element result slab(s)
+        if (o.op != 2 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;   // element result slab(s)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -651,7 +651,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
-        const bool elem_op = (o.op == 1 && dim == 3);
+        // measured (bench, fp64, k = 5): 13.7 M stored entries CSR 49 us / element-wise 61; 21.6 M 102 / 78; 32.8 M 148 / 109; 93 M 472 / 381
+        const bool elem_op = dim == 3 && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
+        st->op_used = elem_op ? 1 : 0;
         if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
             int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);
             launch_elem_slots(n, nt, sy.adjptr, sy.adj, d_slot, s);

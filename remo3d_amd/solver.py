@@ -25,7 +25,7 @@ class RemoError(RuntimeError):
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
               time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0,
-              serialize_solves=False, op="csr") -> RemoOpts:
+              serialize_solves=False, op="auto") -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
     precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
     (BASELINE config 5); inner_digits: decimal digits of <Cr,r> between two residual replacements (0 = library default 3)."""
@@ -47,9 +47,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     o.precision = 1 if precision == "mixed" else 0
     o.inner_digits = int(inner_digits)
     o.serialize_solves = 1 if serialize_solves else 0   # several contexts: one PCG at a time, the others prepare (see the header)
-    if op not in ("csr", "element"):
-        raise ValueError("op must be 'csr' (SpMM on the assembled matrix) or 'element' (element-wise operator, 3D)")
-    o.op = 1 if op == "element" else 0
+    if op not in ("auto", "csr", "element"):
+        raise ValueError("op must be 'auto' (by size), 'csr' (SpMM on the assembled matrix) or 'element' (element-wise operator, 3D)")
+    o.op = {"auto": 0, "element": 1, "csr": 2}[op]
     return o
 
 

@@ -505,3 +505,14 @@ def test_element_operator_is_ignored_in_2d(mesh2d, gpu_ctx):
     assert rca == 0 and rcc == 0
     for u, v in zip(a, c):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_operator_choice_by_size(mesh3d, gpu_ctx):
+    """op = "auto" (the default): CSR product while the matrix stays in the Infinity Cache (17 M stored entries), element-wise above;
+    the statistics say which one ran."""
+    from remo3d_amd import solver
+    _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6))
+    assert rc == 0 and st["nnz"] < 17000000 and st["op_used"] == 0
+    _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, op="element"))
+    assert rc == 0 and st["op_used"] == 1

@@ -39,6 +39,11 @@ template <class T> struct PcgBuffersT {
     // in a row of ~110, so a Chebyshev launch touches three partly used cache lines per row; nullptr -> read A in place
     const int32_t *vb_rowptr = nullptr, *vb_col = nullptr;
     const T *vb_val = nullptr;
+    // fp32 Chebyshev chain inside an fp64 solve (vertex blocks above 32 k rows: the launches are HBM streams there, and a
+    // preconditioner may be inexact); nullptr -> the chain runs in T.  Float copies of the compact block's values and of the
+    // vertex rows' Jacobi factors, chain vectors [nv_coarse * k]
+    const float *c32_val = nullptr, *c32_dinv = nullptr;
+    float *c32_z = nullptr, *c32_res = nullptr, *c32_d[2] = {nullptr, nullptr};
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)

@@ -1123,14 +1123,18 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 // pass).  LAST = 1 (degree 1 only): z = d, nothing else.  LAST = 2: the polynomial's last term needs no
 // product of its own (z_final = z + d + d'), so the launch that forms d' also finishes z and leaves the
 // <r, z> partial sums for the PCG scalars: a polynomial of `degree` terms costs degree - 1 launches.
-template <class T, int K, bool FIRST, int LAST>
+// TC = storage type of the chain (block values, Jacobi factors, directions, residual, running z): T, or float inside an fp64
+// solve (large vertex blocks: the launches are HBM streams there, and a preconditioner may be applied inexactly - the
+// recurrences of x and r never see it).  r (read) and the finished z (written for the direction kernel) stay in T.
+template <class T, class TC, int K, bool FIRST, int LAST>
 __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const T *__restrict__ val, const T *__restrict__ dinv,
-                                                   const T *__restrict__ d_old, T *__restrict__ d_new,
-                                                   T *__restrict__ z, T *__restrict__ res, double c1_, double c2_, double inv_theta_,
+                                                   const TC *__restrict__ val, const TC *__restrict__ dinv,
+                                                   const TC *__restrict__ d_old, TC *__restrict__ d_new,
+                                                   TC *__restrict__ zc, TC *__restrict__ res, T *__restrict__ z, double c1_, double c2_, double inv_theta_,
                                                    T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit, int step) {
-    const T c1 = T(c1_), c2 = T(c2_), inv_theta = T(inv_theta_);
+    const TC c1 = TC(c1_), c2 = TC(c2_), inv_theta = TC(inv_theta_);
     constexpr int LPR = 8, RPB = 256 / LPR;
+    constexpr bool SAME = sizeof(T) == sizeof(TC);
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
     if (solve_done(scal, step)) return;
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
@@ -1145,37 +1149,45 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
     for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
         const int64_t at = row * K + mycol;
-        T di = T(0), rr = T(0), dold_in = T(0), z_in = T(0), res_in = T(0);
+        TC di = TC(0), dold_in = TC(0), z_in = TC(0), res_in = TC(0);
+        T rr = T(0);
         if (mine) {
             di = dinv[row];
-            if (commit) {   // the update launch ran the FIRST step and left the new vertex residual in d_new (free until this
-                rr = d_new[at];   // launch writes it): r could not take it while the neighbours' rows were still gathering r
+            if (SAME && commit) {   // the update launch ran the FIRST step and left the new vertex residual in d_new (free until this
+                rr = T(d_new[at]);  // launch writes it): r could not take it while the neighbours' rows were still gathering r
                 r[at] = rr;
             } else {
                 rr = r[at];
             }
-            if (!FIRST) { dold_in = d_old[at]; z_in = z[at]; res_in = res[at]; }
+            if (!FIRST) { dold_in = d_old[at]; z_in = zc[at]; res_in = res[at]; }
         }
-        T t[K];
+        TC t[K];
 #pragma unroll
-        for (int c = 0; c < K; ++c) t[c] = T(0);
+        for (int c = 0; c < K; ++c) t[c] = TC(0);
         for (int32_t p = rs + sub; p < re; p += LPR) {
             const int32_t j = col[p];
             if (j >= nv) break;  // columns ascend: the vertex block leads the row
-            const T v = FIRST ? val[p] * dinv[j] * inv_theta : val[p];
-            const T *dj = (FIRST ? r : d_old) + int64_t(j) * K;
+            const TC v = FIRST ? val[p] * dinv[j] * inv_theta : val[p];
+            if (FIRST) {
+                const T *dj = r + int64_t(j) * K;
 #pragma unroll
-            for (int c = 0; c < K; ++c) t[c] += v * dj[c];
+                for (int c = 0; c < K; ++c) t[c] += v * TC(dj[c]);
+            } else {
+                const TC *dj = d_old + int64_t(j) * K;
+#pragma unroll
+                for (int c = 0; c < K; ++c) t[c] += v * dj[c];
+            }
         }
         TReduce<K, LPR>::run(t, sub);
         if (mine) {
-            const T dold = FIRST ? di * rr * inv_theta : dold_in;
-            T zi = FIRST ? dold : z_in + dold;
-            const T ri = (FIRST ? rr : res_in) - t[0];
-            const T dn = c1 * dold + c2 * di * ri;
+            const TC dold = FIRST ? di * TC(rr) * inv_theta : dold_in;
+            TC zi = FIRST ? dold : z_in + dold;
+            const TC ri = (FIRST ? TC(rr) : res_in) - t[0];
+            const TC dn = c1 * dold + c2 * di * ri;
             if (LAST == 2) zi += dn;
-            z[at] = LAST ? zi / di : zi;   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
-            if (!LAST) {
+            if (LAST) z[at] = T(zi / di);   // LAST: stored pre-divided by dinv so the direction kernel treats it like r
+            else {
+                zc[at] = zi;
                 res[at] = ri;
                 d_new[at] = dn;
             }
@@ -1615,6 +1627,8 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
     const int launches = b.cheb_degree > 1 ? b.cheb_degree - 1 : 1;   // the last term rides on the launch before it
     const int32_t *vrow = b.vb_rowptr ? b.vb_rowptr : A.rowptr, *vcol = b.vb_rowptr ? b.vb_col : A.col;   // compact vertex block if there is one
     const T *vval = b.vb_rowptr ? b.vb_val : A.val;
+    // fp32 chain inside an fp64 solve: needs the compact block (its float copy), never together with the folded first step
+    const bool chain32 = sizeof(T) == 8 && b.c32_val != nullptr && b.vb_rowptr != nullptr && !first_done;
     for (int j = 0; j < launches; ++j) {
         const double rho_new = 1.0 / (2.0 * sig - rho);
         const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
@@ -1630,8 +1644,13 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
         const int64_t g_rows = (b.nv_coarse + 31) / 32;
         const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
 #define REMO_CHEB(F, L)                                                                                                                             \
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, vval, b.dinv, dold, dnew, \
-                                        b.cz, b.cres, c1, c2, inv_theta, b.r, part, b.rz0, commit, step))
+    if (chain32) {                                                                                                                                  \
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, float, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, b.c32_val, b.c32_dinv, \
+                                            (const float *)b.c32_d[j & 1], b.c32_d[(j + 1) & 1], b.c32_z, b.c32_res, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, 0, step)); \
+    } else {                                                                                                                                        \
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, vval, b.dinv, dold, dnew, \
+                                            b.cz, b.cres, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, commit, step));                                     \
+    }
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
         else if (last) { REMO_CHEB(false, 2); }

@@ -135,6 +135,7 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
+int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
@@ -508,6 +509,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
+        need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;
         if (o.precision == 1)
@@ -634,6 +636,16 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (want_compact && h_vb[0] == 0 && h_vb[1] > 0) { buf.vb_rowptr = vb_rowptr; buf.vb_col = vb_col; buf.vb_val = vb_val; }
+        // fp32 Chebyshev chain inside the fp64 solve (remo_debug_tune key 15: 0 = off): where the chain's launches are HBM streams
+        // (no folded first step: more than 32 k vertex rows) and the compact block exists
+        if (g_chain32 && o.precision == 0 && buf.vb_rowptr && (buf.nv_coarse > 32768 || g_chain32 == 2)) {   // 2: forced (tests)
+            float *v32c = ctx->take<float>(size_t(h_vb[1]) + 4), *d32c = ctx->take<float>(size_t(buf.nv_coarse) + 4);
+            launch_to_float(h_vb[1], buf.vb_val, v32c, s);
+            launch_to_float(buf.nv_coarse, d_dinv, d32c, s);
+            buf.c32_val = v32c; buf.c32_dinv = d32c;
+            buf.c32_z = ctx->take<float>(nc); buf.c32_res = ctx->take<float>(nc);
+            buf.c32_d[0] = ctx->take<float>(nc); buf.c32_d[1] = ctx->take<float>(nc);
+        }
         if (two_level) {
             double lmax;
             std::memcpy(&lmax, &h_bound, sizeof lmax);
@@ -932,6 +944,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 8) set_symbolic_tuning(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
+    else if (key == 15) g_chain32 = value;
     else set_spmm_tuning(key, value);
 }
 

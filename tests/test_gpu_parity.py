@@ -516,3 +516,26 @@ def test_operator_choice_by_size(mesh3d, gpu_ctx):
     assert rc == 0 and st["nnz"] < 17000000 and st["op_used"] == 0
     _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, op="element"))
     assert rc == 0 and st["op_used"] == 1
+
+
+@pytest.mark.gpu
+def test_fp32_chebyshev_chain_inside_the_fp64_solve(mesh3d, gpu_ctx):
+    """Above 32 k vertex rows the Chebyshev launches of an fp64 solve run in fp32 storage (remo_debug_tune key 15; forced here on the
+    small mesh together with the compact vertex block and without the folded first step): an inexactly applied preconditioner
+    changes the iteration slightly, not the solution."""
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        res = {}
+        L.remo_debug_tune(9, 0); L.remo_debug_tune(13, 2)
+        for mode in (0, 2):
+            L.remo_debug_tune(15, mode)
+            assert b.run(solver.make_opts(rtol=1e-11, maxsteps=5000)) == 0
+            res[mode] = (np.concatenate(b.fetch()), b.stats["pcg_steps"], b.true_relres())
+        assert np.allclose(res[0][0], res[2][0], rtol=1e-8, atol=0)
+        assert abs(res[0][1] - res[2][1]) <= max(3, res[0][1] // 20), (res[0][1], res[2][1])
+        assert np.max(res[2][2]) < 5e-11
+    finally:
+        L.remo_debug_tune(9, 1); L.remo_debug_tune(13, 1); L.remo_debug_tune(15, 1)
+        b.close()

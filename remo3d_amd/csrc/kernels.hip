@@ -716,9 +716,14 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
     const int lane = threadIdx.x & 63;
     const int es = lane / NL, c0 = 2 * (lane - es * NL);
     const bool two = c0 + 1 < K;                          // the last lane of an odd k carries one column
-    const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     if (es >= EPW) return;
-    for (int64_t e = wave * EPW + es; e < nt; e += nwaves * EPW) {
+    // Workgroups b, b + 8, ... share an XCD and its L2: every XCD takes ONE contiguous eighth of the elements (elements that are
+    // close in the list are close in the mesh: the x rows they share are served by that L2, and the 40-byte slab rows that
+    // share a 128-byte line are written through the same L2), every workgroup one contiguous chunk of it.
+    const int G = int(gridDim.x);
+    const int vb = (G & 7) == 0 ? int(blockIdx.x & 7) * (G >> 3) + int(blockIdx.x >> 3) : int(blockIdx.x);
+    const int64_t chunk = (nt + G - 1) / G, e_end = (int64_t(vb) + 1) * chunk < nt ? (int64_t(vb) + 1) * chunk : nt;
+    for (int64_t e = int64_t(vb) * chunk + int64_t(threadIdx.x >> 6) * EPW + es; e < e_end; e += int64_t(blockDim.x >> 6) * EPW) {
         int32_t ed[20], sl[20];
         {
             const int4 *pe = reinterpret_cast<const int4 *>(eldof + e * 20), *ps = reinterpret_cast<const int4 *>(slot + e * 20);   // 80-byte records: 16-byte aligned
@@ -750,9 +755,9 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const uint32_t off = sl[i] >= 0 ? (uint32_t(sl[i]) * K + c0) * S : kOutOfRange;
-            T w1[1] = {y[i].x}, w2[1] = {y[i].y};
-            buf_store<T, 1>(ry, off, w1);
-            buf_store<T, 1>(ry, two ? off + S : kOutOfRange, w2);
+            T w1[1] = {y[i].x}, w2[2] = {y[i].x, y[i].y};
+            buf_store<T, 2>(ry, two ? off : kOutOfRange, w2);       // one store of both columns, or of the lone last column
+            buf_store<T, 1>(ry, two ? kOutOfRange : off, w1);
         }
     }
 }
@@ -803,7 +808,7 @@ template <class T, int K> static void elem_dispatch(const CsrViewT<T> &A, const 
     constexpr int EPW = 64 / ((K + 1) / 2);
     int64_t g1 = (E.nt + 4 * EPW - 1) / (4 * EPW);
     if (g1 > 4096) g1 = 4096;
-    if (g1 < 1) g1 = 1;
+    g1 = (g1 + 7) / 8 * 8;       // whole residue classes mod 8: one per XCD
     hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
     if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
     else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);

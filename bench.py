@@ -325,6 +325,7 @@ def main():
                          "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
+    ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip.h lists the keys)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
@@ -346,7 +347,7 @@ def main():
     import numpy as np
     strong = args.total_depths > 0
     dynamic = args.schedule == "dynamic" and world > 1
-    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune and args.op == "auto"
+    extras = (world == 1) and not args.no_extras and args.streams == 1 and args.precision == "fp64" and args.mesh == "lattice" and not args.tune and args.op == "auto" and not args.coarse
     extra_specs = []
     if extras and args.sizes:
         for spec in args.sizes.split(","):
@@ -395,7 +396,8 @@ def main():
     stride = max(1, args.event_stride)
     opts = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                             time_kernels=0 if args.no_events else stride, precision=args.precision,
-                            serialize_solves=(args.streams > 1 and args.overlap == "prepare"), op=args.op)
+                            serialize_solves=(args.streams > 1 and args.overlap == "prepare"), op=args.op,
+                            coarse_degree=int(args.coarse.split(",")[0]) if args.coarse else 0, coarse_ratio=int(args.coarse.split(",")[1]) if args.coarse else 0)
     work = wl["work"]
     n_depths = len(wl["depths"])
     runner = Runner(work, n_depths, local, opts, streams=args.streams, schedule=args.schedule, all_resident=dynamic)

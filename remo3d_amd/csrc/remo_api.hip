@@ -664,7 +664,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
         // measured (bench, fp64, k = 5): 13.7 M stored entries CSR 49 us / element-wise 61; 21.6 M 102 / 78; 32.8 M 148 / 109; 93 M 472 / 381
-        const bool elem_op = dim == 3 && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
+        // (its buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
+        const bool elem_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
+        const bool elem_op = dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
         st->op_used = elem_op ? 1 : 0;
         if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
             int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);

@@ -43,7 +43,6 @@ template <class T> struct PcgBuffersT {
     // preconditioner may be inexact); nullptr -> the chain runs in T.  Float copies of the compact block's values and of the
     // vertex rows' Jacobi factors, chain vectors [nv_coarse * k]
     const float *c32_val = nullptr, *c32_dinv = nullptr;
-    const float *c32_sq_a = nullptr, *c32_sq_b = nullptr;   // float copies of the squared block (paired steps, 2D)
     float *c32_z = nullptr, *c32_res = nullptr, *c32_d[2] = {nullptr, nullptr};
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;

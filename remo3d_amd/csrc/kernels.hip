@@ -1472,17 +1472,15 @@ void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int3
 //   t1 = A w, t2 = B w;   z += (a + b) w - a b D^-1 t1;   w' = w - (a + b) D^-1 t1 + a b D^-1 t2
 // FIRST: z = 0, w = D^-1 r formed on the fly; LAST: z is stored divided by dinv (the direction kernel treats it like
 // r) and the <r, z> partial sums are left for the PCG scalars.
-// TC as in k_cheb_step: the storage type of the chain (T, or float inside an fp64 solve); r and the finished z stay in T.
-template <class T, class TC, int K, int LPR, bool FIRST, bool LAST>
+template <class T, int K, int LPR, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                   const TC *__restrict__ va, const TC *__restrict__ vb, const TC *__restrict__ dinv,
-                                                   const TC *__restrict__ w_old, TC *__restrict__ w_new, TC *__restrict__ zc, T *__restrict__ z,
-                                                   double ab_sum_, double ab_prod_, const T *__restrict__ r, double *__restrict__ part,
-                                                   const double *__restrict__ scal, int step) {
+                                                   const T *__restrict__ va, const T *__restrict__ vb, const T *__restrict__ dinv,
+                                                   const T *__restrict__ w_old, T *__restrict__ w_new, T *__restrict__ z, double ab_sum_, double ab_prod_,
+                                                   const T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int step) {
     constexpr int RPB = 256 / LPR, U = 2;
     static_assert(K <= LPR, "one column per lane after the transposing reduction");
     if (solve_done(scal, step)) return;
-    const TC ab_sum = TC(ab_sum_), ab_prod = TC(ab_prod_);
+    const T ab_sum = T(ab_sum_), ab_prod = T(ab_prod_);
     const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     int idx[K], own[K];
     towner_init<K, LPR>(idx, own, sub);
@@ -1492,41 +1490,34 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
     for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
         const int32_t rs = rowptr[row], re = rowptr[row + 1];
         const int64_t at = row * K + mycol;
-        TC di = TC(0), wi = TC(0), zi = TC(0);
-        T rr = T(0);
+        T di = T(0), wi = T(0), zi = T(0), rr = T(0);
         if (mine) {
             di = dinv[row];
             if (FIRST || LAST) rr = r[at];
-            wi = FIRST ? di * TC(rr) : w_old[at];
-            if (!FIRST) zi = zc[at];
+            wi = FIRST ? di * rr : w_old[at];
+            if (!FIRST) zi = z[at];
         }
-        TC t1[K], t2[K];
+        T t1[K], t2[K];
 #pragma unroll
-        for (int c = 0; c < K; ++c) { t1[c] = TC(0); t2[c] = TC(0); }
+        for (int c = 0; c < K; ++c) { t1[c] = T(0); t2[c] = T(0); }
         for (int32_t p0 = rs + sub; p0 < re; p0 += U * LPR) {   // U passes of loads in flight, as in the SpMM
             int32_t j[U];
-            TC a[U], b[U], w[U][K];
+            T a[U], b[U], w[U][K];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int32_t p = p0 + u * LPR;
-                j[u] = -1; a[u] = TC(0); b[u] = TC(0);
+                j[u] = -1; a[u] = T(0); b[u] = T(0);
                 if (p < re) { j[u] = col[p]; a[u] = va[p]; b[u] = vb[p]; }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int c = 0; c < K; ++c) w[u][c] = TC(0);
+                for (int c = 0; c < K; ++c) w[u][c] = T(0);
                 if (j[u] >= 0) {
-                    if (FIRST) {
-                        const T *wj = r + int64_t(j[u]) * K;
-                        const TC dj = dinv[j[u]];
+                    const T *wj = (FIRST ? r : w_old) + int64_t(j[u]) * K;
+                    const T dj = FIRST ? dinv[j[u]] : T(1);
 #pragma unroll
-                        for (int c = 0; c < K; ++c) w[u][c] = dj * TC(wj[c]);
-                    } else {
-                        const TC *wj = w_old + int64_t(j[u]) * K;
-#pragma unroll
-                        for (int c = 0; c < K; ++c) w[u][c] = wj[c];
-                    }
+                    for (int c = 0; c < K; ++c) w[u][c] = FIRST ? dj * wj[c] : wj[c];
                 }
             }
 #pragma unroll
@@ -1537,12 +1528,9 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
         TReduce<K, LPR>::run(t1, sub);
         TReduce<K, LPR>::run(t2, sub);
         if (mine) {
-            const TC zn = zi + ab_sum * wi - ab_prod * di * t1[0];
-            if (LAST) z[at] = T(zn / di);
-            else {
-                zc[at] = zn;
-                w_new[at] = wi - ab_sum * di * t1[0] + ab_prod * di * t2[0];
-            }
+            const T zn = zi + ab_sum * wi - ab_prod * di * t1[0];
+            z[at] = LAST ? zn / di : zn;
+            if (!LAST) w_new[at] = wi - ab_sum * di * t1[0] + ab_prod * di * t2[0];
             if (LAST) dot += double(rr) * double(zn);
         }
     }
@@ -1609,7 +1597,6 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
         // 3D rows of B hold ~65 entries (32 lanes per row), 2D rows ~19 (8 lanes)
         const int g_last = cheb_grid(b.nv_coarse);
         double *part = part_slot + int64_t(b.nb_vec) * k;
-        const bool sq32 = sizeof(T) == 8 && b.c32_sq_a != nullptr;     // fp32 chain inside an fp64 solve
         for (int j = 0; j < np; ++j) {
             // roots of the shifted Chebyshev polynomial, paired from the two ends of the interval inwards
             const double r1 = theta - delta * cos(M_PI * (2.0 * (j + 1) - 1.0) / (2.0 * m));
@@ -1621,14 +1608,8 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
             // only the LAST launch leaves partial sums, so only it is tied to the cheb_grid slots
             auto grid_for = [&](int lpr) { int64_t gg = (b.nv_coarse + 256 / lpr - 1) / (256 / lpr); if (last && gg > g_last) gg = g_last; if (gg > 4096) gg = 4096; return int(gg); };
 #define REMO_CHEB2(LPRV, F, L)                                                                                                                        \
-    if (sq32) {                                                                                                                                       \
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_pair<T, float, KK, LPRV, F, L>), dim3(grid_for(LPRV)), dim3(256), 0, s, b.nv_coarse, b.sq_rowptr, b.sq_col, \
-                                            b.c32_sq_a, b.c32_sq_b, b.c32_dinv, (const float *)b.c32_d[j & 1], b.c32_d[(j + 1) & 1], b.c32_z, b.cz, a + bb, a * bb, \
-                                            (const T *)b.r, part, b.rz0, step));                                                                       \
-    } else {                                                                                                                                          \
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_pair<T, T, KK, LPRV, F, L>), dim3(grid_for(LPRV)), dim3(256), 0, s, b.nv_coarse, b.sq_rowptr, b.sq_col, b.sq_a, \
-                                            b.sq_b, b.dinv, wold, wnew, b.cz, b.cz, a + bb, a * bb, (const T *)b.r, part, b.rz0, step));                   \
-    }
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_pair<T, KK, LPRV, F, L>), dim3(grid_for(LPRV)), dim3(256), 0, s, b.nv_coarse, b.sq_rowptr, b.sq_col, b.sq_a, \
+                                        b.sq_b, b.dinv, wold, wnew, b.cz, a + bb, a * bb, b.r, part, b.rz0, step))
 #define REMO_CHEB2_FL(LPRV)                                 \
     if (first && last) { REMO_CHEB2(LPRV, true, true); }    \
     else if (first) { REMO_CHEB2(LPRV, true, false); }      \

@@ -509,7 +509,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
-        need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8 + 200 * 8);          // fp32 Chebyshev chain of the fp64 solve (+ float copies of the squared block)
+        need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;
         if (o.precision == 1)
@@ -657,16 +657,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             buf.sq_rowptr = sq_rowptr; buf.sq_col = sq_col; buf.sq_a = sq_a; buf.sq_b = sq_b;
             const double avg = double(h_sq[1]) / double(buf.nv_coarse > 0 ? buf.nv_coarse : 1);
             buf.sq_lanes = g_sq_lanes ? g_sq_lanes : (avg > 40.0 ? 32 : (avg > 14.0 ? 16 : 8));
-            // fp32 chain inside the fp64 solve (key 15): in 2D the paired launches are half of a PCG step (6 x 14 + 16 + 19 of 220 us
-            // at 80 k vertices); block values, Jacobi factors and the chain's vectors in fp32
-            if (g_chain32 && o.precision == 0) {
-                float *a32 = ctx->take<float>(size_t(h_sq[1]) + 4), *b32 = ctx->take<float>(size_t(h_sq[1]) + 4), *d32c = ctx->take<float>(size_t(buf.nv_coarse) + 4);
-                launch_to_float(h_sq[1], sq_a, a32, s);
-                launch_to_float(h_sq[1], sq_b, b32, s);
-                launch_to_float(buf.nv_coarse, d_dinv, d32c, s);
-                buf.c32_sq_a = a32; buf.c32_sq_b = b32; buf.c32_dinv = d32c;
-                buf.c32_z = ctx->take<float>(nc); buf.c32_d[0] = ctx->take<float>(nc); buf.c32_d[1] = ctx->take<float>(nc);
-            }
         }
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");

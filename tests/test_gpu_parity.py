@@ -539,26 +539,3 @@ def test_fp32_chebyshev_chain_inside_the_fp64_solve(mesh3d, gpu_ctx):
     finally:
         L.remo_debug_tune(9, 1); L.remo_debug_tune(13, 1); L.remo_debug_tune(15, 1)
         b.close()
-
-
-@pytest.mark.gpu
-def test_fp32_paired_chain_in_2d(mesh2d, gpu_ctx):
-    """2D: the paired Chebyshev launches on the squared vertex block run in fp32 storage inside the fp64 solve by default
-    (key 15): same potentials as with the fp64 chain, step counts within a few per cent, true residual at the tolerance."""
-    from remo3d_amd import _lib, solver
-    L = _lib.load()
-    b = gpu_ctx.batch(mesh2d, SIGMA3, SRC, EVAL)
-    try:
-        res = {}
-        for mode in (0, 1):
-            L.remo_debug_tune(15, mode)
-            for degree, ratio in ((16, 600), (32, 2400)):
-                assert b.run(solver.make_opts(rtol=1e-11, maxsteps=5000, coarse_degree=degree, coarse_ratio=ratio)) == 0
-                res[(mode, degree)] = (np.concatenate(b.fetch()), b.stats["pcg_steps"], b.true_relres())
-        for degree in (16, 32):
-            assert np.allclose(res[(0, degree)][0], res[(1, degree)][0], rtol=1e-8, atol=0)
-            assert abs(res[(0, degree)][1] - res[(1, degree)][1]) <= max(3, res[(0, degree)][1] // 10), (degree, res[(0, degree)][1], res[(1, degree)][1])
-            assert np.max(res[(1, degree)][2]) < 5e-11
-    finally:
-        L.remo_debug_tune(15, 1)
-        b.close()

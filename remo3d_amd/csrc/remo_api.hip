@@ -544,8 +544,14 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // 24 k, (12-16, 300-600) at 80 k; fine scan after the first / last step lost their launches (tools/scan_coarse3d_fine.py):
         // (5, 70-90) at 12.8 k, (8, 120-160) at 27 k (7: +3 %, 9: +4.5 %).  2D (launch-bound steps, paired Chebyshev launches): (16, 600).
         const double nv_rel = double(sy.nvfree > 0 ? sy.nvfree : 1) / 12600.0;
-        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.9)))) : 16;
-        const double ratio_default = (dim == 3) ? std::min(1200.0, std::max(60.0, 90.0 * std::pow(nv_rel, 2.0 / 3.0))) : 600.0;
+        // 2D, round 2 (tools/run_2d_batches.py at the 80 k vertices of config 2 with the 0.35 default mesh scale): (16, 600) 173 ms per four
+        // batches, (24, 1200) 162, (32, 2400) 155, 752 / 561 / 446 steps - the product of degree and steps grows slowly, a launch pair costs
+        // 14 us; (16, 600) was the optimum at 25 k vertices: degree ~ sqrt(vertices), ratio ~ vertices, even degrees (paired launches).
+        // The paired (root-product) form must stay in fp64: in fp32 storage it needs MORE steps at degree 16 and breaks down above.
+        const double nv2 = double(sy.nvfree > 0 ? sy.nvfree : 1) / 25000.0;
+        const int deg2 = 2 * int(std::min(16.0, std::max(8.0, std::floor(8.0 * std::sqrt(nv2) + 0.5))));
+        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.9)))) : deg2;
+        const double ratio_default = (dim == 3) ? std::min(1200.0, std::max(60.0, 90.0 * std::pow(nv_rel, 2.0 / 3.0))) : std::min(2400.0, std::max(600.0, 600.0 * nv2 * 1.25));
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : deg_default) : 0;
         buf.cheb_lmax = buf.cheb_lmin = 0.0;
         const size_t nc = size_t(buf.nv_coarse) * kmax + 2;

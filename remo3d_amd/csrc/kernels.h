@@ -61,8 +61,6 @@ template <class T> struct ElemOpT {
     const int32_t *slot = nullptr;    // [nt][20] position of (element, local dof) in the adjacency list, -1 = constrained (launch_elem_slots)
     int64_t nadj = 0;                 // upper bound of the adjacency entries (nt * 20): rows of the slab
     T *Ye = nullptr;                  // [nadj][k] scratch slab: an element's result rows at their adjacency positions
-    double *part_big = nullptr;       // [workgroups of pass 1][8] partial sums of <x, A x> (fused form)
-    int fused = 0;                    // 1: inside the PCG the row sums of the slab are taken by the update launch (launch_pcg_apply)
 };
 void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s);
 
@@ -96,9 +94,6 @@ int choose_lanes_per_row(int64_t n, int64_t nnz);
 // scal != nullptr: the launch belongs to PCG step `step` and returns at once when an earlier step froze every column
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step = 0);
 
-// the CG's q = A p with the <p, q> partials: launch_spmm, or - element-wise operator with `fused` - pass 1 alone (returns true:
-// q is NOT formed, launch_pcg_update sums the slab rows itself and expects ONE row of partials)
-template <class T> bool launch_pcg_apply(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step);
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)
 template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);

@@ -704,14 +704,11 @@ void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint3
 // slots.  ~200 VGPRs: two waves per SIMD.  (One lane per element with all columns in registers - 256 VGPRs + 68 AGPRs,
 // one wave per SIMD - ran 15 cycles per instruction: dependent fp64 chains and SGPR spills with nothing to hide them;
 // one lane per (element, column) needs 2.6x the requests.)
-// DOT: also leaves per-workgroup partial sums of <x, A x> = sum over elements of X_e . (K_e X_e) - the CG's <p, Ap> without the
-// row-summed product, which lets the PCG update launch do the row sums itself (launch_pcg_apply).
-template <class T, int K, bool DOT>
+template <class T, int K>
 __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64_t nadj, const int32_t *__restrict__ eldof, const int32_t *__restrict__ slot,
                                                     const double *__restrict__ C, const T *__restrict__ x, T *__restrict__ Ye,
-                                                    double *__restrict__ part_big, const double *__restrict__ scal, int step) {
+                                                    const double *__restrict__ scal, int step) {
     if (scal && solve_done(scal, step)) return;
-    double dot0 = 0.0, dot1 = 0.0;
     typedef T T2 __attribute__((ext_vector_type(2)));
     constexpr uint32_t S = sizeof(T);
     constexpr int NL = (K + 1) / 2, EPW = 64 / NL;       // lanes per element, elements per wave
@@ -719,13 +716,14 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
     const int lane = threadIdx.x & 63;
     const int es = lane / NL, c0 = 2 * (lane - es * NL);
     const bool two = c0 + 1 < K;                          // the last lane of an odd k carries one column
+    if (es >= EPW) return;
     // Workgroups b, b + 8, ... share an XCD and its L2: every XCD takes ONE contiguous eighth of the elements (elements that are
     // close in the list are close in the mesh: the x rows they share are served by that L2, and the 40-byte slab rows that
     // share a 128-byte line are written through the same L2), every workgroup one contiguous chunk of it.
     const int G = int(gridDim.x);
     const int vb = (G & 7) == 0 ? int(blockIdx.x & 7) * (G >> 3) + int(blockIdx.x >> 3) : int(blockIdx.x);
     const int64_t chunk = ((nt + G - 1) / G + 4 * EPW - 1) / (4 * EPW) * (4 * EPW), e_end = (int64_t(vb) + 1) * chunk < nt ? (int64_t(vb) + 1) * chunk : nt;
-    for (int64_t e = int64_t(vb) * chunk + int64_t(threadIdx.x >> 6) * EPW + es; es < EPW && e < e_end; e += int64_t(blockDim.x >> 6) * EPW) {
+    for (int64_t e = int64_t(vb) * chunk + int64_t(threadIdx.x >> 6) * EPW + es; e < e_end; e += int64_t(blockDim.x >> 6) * EPW) {
         int32_t ed[20], sl[20];
         {
             const int4 *pe = reinterpret_cast<const int4 *>(eldof + e * 20), *ps = reinterpret_cast<const int4 *>(slot + e * 20);   // 80-byte records: 16-byte aligned
@@ -760,28 +758,8 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
             T w1[1] = {y[i].x}, w2[2] = {y[i].x, y[i].y};
             buf_store<T, 2>(ry, two ? off : kOutOfRange, w2);       // one store of both columns, or of the lone last column
             buf_store<T, 1>(ry, two ? kOutOfRange : off, w1);
-            if (DOT) { dot0 += double(xv[i].x) * double(y[i].x); dot1 += double(xv[i].y) * double(y[i].y); }   // x is zero at constrained dofs
         }
     }
-    if (DOT) {
-        __shared__ double smem[16 * K];
-        double dcol[K];
-#pragma unroll
-        for (int c = 0; c < K; ++c) dcol[c] = (es < EPW && c == c0) ? dot0 : ((es < EPW && c == c0 + 1) ? dot1 : 0.0);
-        block_sum<K>(dcol, smem);
-        if (threadIdx.x < K) part_big[int64_t(blockIdx.x) * K + threadIdx.x] = pick<K>(dcol, threadIdx.x);
-    }
-}
-
-// per-workgroup partials of pass 1 (one row per workgroup, thousands of them) -> ONE row the update launch reads; fixed order
-template <int K>
-__global__ void __launch_bounds__(256) k_elem_fold_partials(int nblocks, const double *__restrict__ part_big, double *__restrict__ part_pq,
-                                                            const double *__restrict__ scal, int step) {
-    __shared__ double smem[16 * K];
-    if (scal && solve_done(scal, step)) return;
-    double out[K];
-    reduce_partials<K>(part_big, nblocks, out, smem);
-    if (threadIdx.x < K) part_pq[threadIdx.x] = pick<K>(out, threadIdx.x);
 }
 
 // Pass 2.  One lane per matrix row: the row's contributions are adjacent in the slab (adjacency order = ascending elements:
@@ -830,7 +808,7 @@ template <class T, int K> static void elem_dispatch(const CsrViewT<T> &A, const 
     constexpr int EPW = 64 / ((K + 1) / 2);
     int64_t g1 = (E.nt + 4 * EPW - 1) / (4 * EPW);      // one trip of its four waves per workgroup (a capped grid left a ragged second trip: 249 vs 219 us at 443 k elements)
     g1 = (g1 + 7) / 8 * 8;       // whole residue classes mod 8: one per XCD
-    hipLaunchKernelGGL((k_elem_apply<T, K, false>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, (double *)nullptr, scal, step);
+    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
     if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
     else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
 }
@@ -929,36 +907,6 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 #undef REMO_SPMM_PAIR
 }
 
-// pass 1 with the <x, A x> partials, folded to ONE row of part: the product itself stays in the slab (launch_pcg_apply)
-template <class T, int K> static void elem_apply_dot(const CsrViewT<T> &A, const T *x, double *part, const double *scal, int step, hipStream_t s) {
-    const ElemOpT<T> &E = *A.elem;
-    constexpr int EPW = 64 / ((K + 1) / 2);
-    int64_t g1 = (E.nt + 4 * EPW - 1) / (4 * EPW);
-    g1 = (g1 + 7) / 8 * 8;
-    hipLaunchKernelGGL((k_elem_apply<T, K, true>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, E.part_big, scal, step);
-    hipLaunchKernelGGL((k_elem_fold_partials<K>), dim3(1), dim3(256), 0, s, int(g1), (const double *)E.part_big, part, scal, step);
-}
-
-template <class T> bool launch_pcg_apply(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
-    if (A.elem && A.elem->fused && part) {
-        switch (k) {
-            case 1: elem_apply_dot<T, 1>(A, x, part, scal, step, s); break;
-            case 2: elem_apply_dot<T, 2>(A, x, part, scal, step, s); break;
-            case 3: elem_apply_dot<T, 3>(A, x, part, scal, step, s); break;
-            case 4: elem_apply_dot<T, 4>(A, x, part, scal, step, s); break;
-            case 5: elem_apply_dot<T, 5>(A, x, part, scal, step, s); break;
-            case 6: elem_apply_dot<T, 6>(A, x, part, scal, step, s); break;
-            case 7: elem_apply_dot<T, 7>(A, x, part, scal, step, s); break;
-            default: elem_apply_dot<T, 8>(A, x, part, scal, step, s); break;
-        }
-        return true;      // q = A x is NOT formed: launch_pcg_update sums the slab rows of every matrix row itself
-    }
-    launch_spmm(A, k, x, y, part, scal, nb, s, step);
-    return false;
-}
-template bool launch_pcg_apply<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int);
-template bool launch_pcg_apply<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int);
-
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
     if (A.elem) {     // element-wise operator instead of the stored matrix
         switch (k) {
@@ -1052,17 +1000,13 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t n, ChebArgsT<T> ch, co
     if (threadIdx.x < K) part_rz[blockIdx.x * K + threadIdx.x] = rz[threadIdx.x];
 }
 
-// ELEM: q = A p was left by the element-wise operator as a slab of element results (launch_pcg_apply): row i of q is the sum of
-// the slab rows adjptr[i] .. adjptr[i + 1], formed here on the fly in the operator's fixed order - the row-summed product is
-// never written or read back (three vector passes and a launch less per PCG step).
-template <class T, int K, bool ELEM = false>
+template <class T, int K>
 __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double tol2, int x_only, int nb_spmv, int nb_rz, ChebArgsT<T> ch,
                                                     const double *__restrict__ part_pq, const double *__restrict__ part_rz_cur,
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const T *__restrict__ p,
                                                     const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
-                                                    const T *__restrict__ dinv, FoldArgsT<T> fold,
-                                                    const int32_t *__restrict__ adjptr, const T *__restrict__ slab, int64_t nadj) {
+                                                    const T *__restrict__ dinv, FoldArgsT<T> fold) {
     // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
@@ -1158,35 +1102,15 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         return;
     }
     const int64_t i0 = fold.nb_flat > 0 ? ch.nv : 0;
-    rsrc_t rslab;
-    if constexpr (ELEM) rslab = make_rsrc(slab, uint64_t(nadj) * K * sizeof(T));
 #pragma unroll 2
     for (int64_t i = i0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(nb_flat) * blockDim.x) {
         const T d = dinv[i];
         const bool coarse = i < ch.nv;
-        T qv[K];
-        if constexpr (ELEM) {
-            const int32_t as = adjptr[i], ae = adjptr[i + 1];
-#pragma unroll
-            for (int c = 0; c < K; ++c) qv[c] = T(0);
-            for (int32_t a = as; a < ae; a += 4) {          // four slab rows in flight (past the end: out of range, zero, no request)
-                T v[4][K];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) buf_load<T, K>(rslab, a + u < ae ? uint32_t(a + u) * uint32_t(K * sizeof(T)) : kOutOfRange, v[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int c = 0; c < K; ++c) qv[c] += v[u][c];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < K; ++c) qv[c] = q[i * K + c];
-        }
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const T a = T(alpha[c]);
             const T xi = x[i * K + c] + a * p[i * K + c];
-            const T ri = r[i * K + c] - a * qv[c];
+            const T ri = r[i * K + c] - a * q[i * K + c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
             acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels
@@ -1759,8 +1683,7 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     const ChebArgsT<T> ch = cheb_args(b);
     FoldArgsT<T> fold;
     int grid = g;
-    const bool fused = A.elem && A.elem->fused;      // q = A p is a slab of element results (launch_pcg_apply): its vertex rows cannot be gathered
-    const bool folded = !fused && cheb_first_folds(b);
+    const bool folded = cheb_first_folds(b);
     if (folded) {
         const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
         const double sig = theta / delta, rho = 1.0 / sig, rho_new = 1.0 / (2.0 * sig - rho);
@@ -1770,13 +1693,8 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
         fold.c1 = rho_new * rho; fold.c2 = 2.0 * rho_new / delta;      // the j = 0 coefficients of launch_cheb
         grid = g + int((b.nv_coarse + 31) / 32);   // the vertex workgroups leave no partial sums: one row group each
     }
-    if (fused) {
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK, true>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, 1, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                            b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, A.elem->adjptr, (const T *)A.elem->Ye, A.elem->nadj));
-    } else {
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                            b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, (const int32_t *)nullptr, (const T *)nullptr, int64_t(0)));
-    }
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold));
     launch_cheb(A, k, step, b, nxt, s, folded);
 }
 
@@ -1814,9 +1732,8 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<float> ch = cheb_args(b);
-    const int nbq = (A.elem && A.elem->fused) ? 1 : b.nb_spmv;      // the fused element-wise operator leaves ONE row of <p, Ap> partials
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, nbq, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>(), (const int32_t *)nullptr, (const float *)nullptr, int64_t(0)));
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>()));
     launch_mixed_accumulate(n * k, x64, b.x, 1, s);
     launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s, 0);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0, step));

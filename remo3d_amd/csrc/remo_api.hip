@@ -135,7 +135,6 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
-int g_elem_fused = 1;   // key 16: 1 = inside the PCG the update launch sums the slab rows of the element-wise operator itself (default), 0 = separate row-reduction launch
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
@@ -173,11 +172,11 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
         // time_kernels = k: every k-th SpMM launch is bracketed with events (a bracket costs the stream ~1.5 us)
         if (time_kernels > 0 && (step % time_kernels) == (time_kernels / 2) && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
-            launch_pcg_apply(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
             ev_used += 2;
         } else {
-            launch_pcg_apply(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
         }
         bool replaced = false;
         if constexpr (std::is_same<T, float>::value) {
@@ -506,7 +505,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        if (o.op != 2 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + size_t(nt) * 2 + 16384;   // element result slab(s)
+        if (o.op != 2 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;   // element result slab(s)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -679,8 +678,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);
             launch_elem_slots(n, nt, sy.adjptr, sy.adj, d_slot, s);
             b->elem64 = ElemOpT<double>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, d_slot, nt * 20, ctx->take<double>(size_t(nt) * 20 * size_t(kmax))};
-            b->elem64.part_big = ctx->take<double>((size_t(nt) / 32 + 64) * 8);     // one row per workgroup of pass 1 (>= 32 elements each)
-            b->elem64.fused = g_elem_fused;
             b->A.elem = &b->elem64;
         }
         b->d_val = d_val;
@@ -709,7 +706,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
             if (elem_op) {
                 b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, b->elem64.slot, nt * 20, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
-                b->elem32.part_big = b->elem64.part_big; b->elem32.fused = g_elem_fused;
                 mx.A32.elem = &b->elem32;
             }
             PcgBuffersT<float> &f = mx.b32;
@@ -957,7 +953,6 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;
-    else if (key == 16) g_elem_fused = value;
     else set_spmm_tuning(key, value);
 }
 

@@ -26,6 +26,9 @@ work = []
 for bi in range(0, len(batches), max(1, len(batches) // nb))[:nb]:
     fg, bh, sigma = geometry.select_netgen_data_range(bg, m.formation_model, mud[bi], sim[bi], 50.0)
     work.append((provider(2, 50.0, batches[bi], fg, bh, 0.0), sigma) + tasks.batch_rhs(batches[bi], m.tools)[:2])
+for kv in os.environ.get("REMO_TUNE", "").split():
+    from remo3d_amd import _lib
+    _lib.load().remo_debug_tune(*[int(v) for v in kv.split("=")])
 with solver.Context(0) as ctx:
     for deg, ratio in coarse:
       tot = [0.0, 0]

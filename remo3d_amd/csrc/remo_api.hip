@@ -662,7 +662,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (want_square && h_sq[0] == 0) {   // otherwise (a vertex of very high valence) the one-step launches stay
             buf.sq_rowptr = sq_rowptr; buf.sq_col = sq_col; buf.sq_a = sq_a; buf.sq_b = sq_b;
             const double avg = double(h_sq[1]) / double(buf.nv_coarse > 0 ? buf.nv_coarse : 1);
-            buf.sq_lanes = g_sq_lanes ? g_sq_lanes : (avg > 40.0 ? 32 : (avg > 14.0 ? 16 : 8));
+            buf.sq_lanes = g_sq_lanes ? g_sq_lanes : (avg > 40.0 ? 32 : (avg > 24.0 ? 16 : 8));   // 2D rows of B hold ~19 entries: 8 lanes (two passes in flight) 145 vs 150 ms with 16
         }
         if (h_err & 1) return fail(ctx, REMO_ERR_MESH, "degenerate element or material index out of range");
         if (h_err & 2) return fail(ctx, REMO_ERR_POINT, "source or evaluation point outside the mesh");

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 3
+#define REMO_ABI_VERSION 4
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -82,6 +82,15 @@ typedef struct {
                                    Infinity Cache between launches (more than 17 M stored entries: there the element-wise form takes
                                    24-26 % less time than the CSR product, below it the CSR product is 20 % ahead), else CSR.
                                The matrix is assembled either way (Jacobi diagonal, P1 block of the preconditioner, inspection hooks) */
+    int32_t coarse;         /* "multigrid": the solver of the P1 (vertex) block.
+                               1 = Chebyshev polynomial (coarse_degree, coarse_ratio);
+                               2 = one V(1,1) cycle of a smoothed-aggregation multigrid hierarchy built per batch on the device
+                                   (distance-2 independent-set aggregates, Galerkin products, dense coarsest solve);
+                               0 = by dimension (default): the cycle in 2D (graded axisymmetric meshes: 40 % fewer PCG steps than
+                                   the polynomial of degree 28 at a quarter of its launches), the polynomial in 3D (there it is
+                                   within 15 % of an exact vertex solve at degree 5-13 and the cycle gains nothing).
+                               If the hierarchy cannot be built (a vertex of extreme valence) 0 falls back to the polynomial, 2 fails */
+    int32_t reserved_opts;
 } remo_opts_t;
 
 typedef struct {
@@ -109,7 +118,7 @@ typedef struct {
                             i.e. what a bracket measures beyond the kernel it encloses             */
     int64_t refinement_cycles; /* mixed precision: fp32 inner solves that contributed a correction (all chunks) */
     int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 1 = element by element (remo_opts_t.op) */
-    int32_t reserved;
+    int32_t coarse_used; /* vertex-block solver of the run: 0 = none ("local"), 1 = Chebyshev polynomial, 2 = multigrid cycle */
 } remo_stats_t;
 
 typedef struct remo_ctx remo_ctx_t;
@@ -196,7 +205,7 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
  * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
  * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
  * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact).  Process-global. */
+ * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides).  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

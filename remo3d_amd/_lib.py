@@ -25,7 +25,7 @@ class RemoOpts(C.Structure):
     _fields_ = [("preconditioner", C.c_int32), ("condense", C.c_int32), ("maxsteps", C.c_int32),
                 ("check_every", C.c_int32), ("rtol", C.c_double), ("time_kernels", C.c_int32),
                 ("coarse_degree", C.c_int32), ("coarse_ratio", C.c_int32), ("precision", C.c_int32), ("inner_digits", C.c_int32),
-                ("serialize_solves", C.c_int32), ("op", C.c_int32)]
+                ("serialize_solves", C.c_int32), ("op", C.c_int32), ("coarse", C.c_int32), ("reserved_opts", C.c_int32)]
 
 
 class RemoStats(C.Structure):
@@ -36,7 +36,7 @@ class RemoStats(C.Structure):
                 ("ms_solve", C.c_double), ("ms_eval", C.c_double), ("ms_total", C.c_double),
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_double),
                 ("pcg_steps", C.c_int64), ("spmv_ms_raw", C.c_double), ("event_overhead_ms", C.c_double),
-                ("refinement_cycles", C.c_int64), ("op_used", C.c_int32), ("reserved", C.c_int32)]
+                ("refinement_cycles", C.c_int64), ("op_used", C.c_int32), ("coarse_used", C.c_int32)]
 
     def as_dict(self):
         d = {}

@@ -1,0 +1,803 @@
+// amg.hip — smoothed-aggregation multigrid on the P1 (vertex) block, gfx950.
+//
+// Why: in 2D (graded axisymmetric meshes, 80 k vertices at config 2) the Chebyshev polynomial on the vertex block needs degree
+// 28 on [lmax / 2400, lmax] - 14 paired launches, two thirds of a PCG step - and still takes twice the steps of an exact
+// vertex solve (offline, tools/amg_study_2d.py: exact 58, Chebyshev(28) 119, this cycle 71 steps at 3.7 sweeps of the block).
+//
+// Setup per batch (the matrix changes with every batch), all on the device, deterministic (no floating-point atomics):
+//   aggregation   distance-2 maximal independent set of the matrix graph by hashed priorities (Bell / Dalton / Olson 2012):
+//                 roots, then their neighbours, then the neighbours' neighbours by the strongest connection
+//   prolongator   P = (I - 4 / (3 lmax) D^-1 A) P0, one generic row-wise sparse product (LDS hash set per wave for the
+//                 pattern, sorted; values by sorted-row lookups in a fixed order), R = P^T by a radix sort of (column, row)
+//   coarse matrix A' = R (A P), two more products
+//   coarsest      dense inverse (Gauss-Jordan in LDS, <= 64 rows)
+// Cycle: V(1,1) with damped Jacobi (omega = 1.6 / lmax, the one-term Chebyshev polynomial of [lmax / 4, lmax]), symmetric, so
+// the PCG sees a fixed symmetric positive definite preconditioner.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "amg.h"
+#include "kernels.h"
+#include "wave_util.h"
+
+namespace remo {
+namespace {
+
+#define HIP_OK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// LDS hash slots per wave of the sparse product: 128 first (rows of at most 64 distinct columns), 512 when a row overflows
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ bool amg_done(const double *scal, int step) {
+    if (!scal) return false;
+    const int d = reinterpret_cast<const int *>(scal + kDoneSlot)[0];
+    return d != 0 && d <= step;
+}
+
+__device__ __forceinline__ int32_t lower_bound_i32(const int32_t *__restrict__ a, int32_t lo, int32_t hi, int32_t key) {
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- leading block -> compact CSR ---------------------------------------------------------------------------------------
+template <int PASS>
+__global__ void __launch_bounds__(256) k_block_copy(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, int32_t *__restrict__ cnt, const int32_t *__restrict__ orp,
+                                                    int32_t *__restrict__ oc, double *__restrict__ ov) {
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= nv) return;
+    const int32_t rs = rowptr[row], re = rowptr[row + 1];
+    if (PASS == 0) {
+        cnt[row] = lower_bound_i32(col, rs, re, int32_t(nv)) - rs;
+    } else {
+        const int32_t at = orp[row], len = orp[row + 1] - at;
+        for (int32_t e = 0; e < len; ++e) { oc[at + e] = col[rs + e]; ov[at + e] = val[rs + e]; }
+    }
+}
+
+// Jacobi factors and the Gershgorin bound of D^-1 A; flag |= 1 when a diagonal entry is missing or not positive
+__global__ void __launch_bounds__(256) k_level_diag(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, double *__restrict__ dinv, unsigned long long *bound_bits,
+                                                    int32_t *flag) {
+    double m = 0.0;
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row < n) {
+        double s = 0.0, d = 0.0;
+        for (int32_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+            s += fabs(val[p]);
+            if (col[p] == row) d = val[p];
+        }
+        if (!(d > 0.0)) { atomicOr(flag, 1); d = 1.0; }
+        dinv[row] = 1.0 / d;
+        m = s / d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bound_bits, (unsigned long long)__double_as_longlong(m));   // positive doubles order like their bits
+}
+
+// ---- aggregation: distance-2 maximal independent set ---------------------------------------------------------------------
+// tuple = state (2 bits: 2 root, 1 undecided, 0 removed) | hashed priority (30 bits) | index (32 bits): unique, so maxima are too
+constexpr uint64_t kTupMask = (uint64_t(1) << 62) - 1;
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_mis_init(int64_t n, uint64_t *__restrict__ tup) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) tup[i] = (uint64_t(1) << 62) | (uint64_t(hash_u32(uint32_t(i)) >> 2) << 32) | uint64_t(uint32_t(i));
+}
+
+__global__ void __launch_bounds__(256) k_mis_max(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const uint64_t *__restrict__ tup, uint64_t *__restrict__ m1) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t m = tup[i];
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) { const uint64_t t = tup[col[p]]; m = t > m ? t : m; }
+    m1[i] = m;
+}
+
+// second hop + decision; tup is updated in place (the other threads read m1 only); undecided[0] counts what is left
+__global__ void __launch_bounds__(256) k_mis_update(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    uint64_t *__restrict__ tup, const uint64_t *__restrict__ m1, int32_t *undecided) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t t = tup[i];
+    if ((t >> 62) != 1) return;
+    uint64_t m = m1[i];
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) { const uint64_t v = m1[col[p]]; m = v > m ? v : m; }
+    if (m == t) tup[i] = (uint64_t(2) << 62) | (t & kTupMask);
+    else if ((m >> 62) == 2) tup[i] = t & kTupMask;
+    else atomicAdd(undecided, 1);
+}
+
+__global__ void __launch_bounds__(256) k_mis_flags(int64_t n, const uint64_t *__restrict__ tup, int32_t *__restrict__ isroot) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) isroot[i] = (tup[i] >> 62) == 2 ? 1 : 0;
+}
+
+// roots take their number, the others the root neighbour of the highest priority (-1: none)
+__global__ void __launch_bounds__(256) k_agg_near(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                  const uint64_t *__restrict__ tup, const int32_t *__restrict__ id, int32_t *__restrict__ agg) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((tup[i] >> 62) == 2) { agg[i] = id[i]; return; }
+    uint64_t best = 0;
+    int32_t bj = -1;
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+        const int32_t j = col[p];
+        const uint64_t t = tup[j];
+        if ((t >> 62) == 2 && t > best) { best = t; bj = j; }
+    }
+    agg[i] = bj >= 0 ? id[bj] : -1;
+}
+
+// the rest: the aggregate of the neighbour with the strongest connection (ties: the lower index, columns ascend)
+__global__ void __launch_bounds__(256) k_agg_far(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ agg_in, int32_t *__restrict__ agg_out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t a = agg_in[i];
+    if (a < 0) {
+        double w = -1.0;
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            const int32_t j = col[p];
+            if (j == i) continue;
+            const int32_t aj = agg_in[j];
+            const double v = fabs(val[p]);
+            if (aj >= 0 && v > w) { w = v; a = aj; }
+        }
+    }
+    agg_out[i] = a;
+}
+
+// S = I - wp D^-1 A on the pattern of A, and the tentative prolongator (one unit entry per row) as CSR
+__global__ void __launch_bounds__(256) k_smoothing_factor(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const double *__restrict__ val, const double *__restrict__ dinv, double wp,
+                                                          double *__restrict__ sval, const int32_t *__restrict__ agg, int32_t *__restrict__ p0rp,
+                                                          int32_t *__restrict__ p0c, double *__restrict__ p0v) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    p0rp[i] = int32_t(i);
+    if (i == n) return;
+    const double f = wp * dinv[i];
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) sval[p] = (col[p] == i ? 1.0 : 0.0) - f * val[p];
+    const int32_t a = agg[i];
+    p0c[i] = a >= 0 ? a : 0;
+    p0v[i] = a >= 0 ? 1.0 : 0.0;
+}
+
+// ---- generic sparse product C = X Y, one wave per row of X ----------------------------------------------------------------
+// PASS 0 counts the distinct columns of every row; PASS 1 (row offsets known) writes them sorted with their values.
+// Columns of Y rows ascend (binary search); X rows in any order.  flag |= 1: a row does not fit the hash table.
+template <int PASS, int SLOTS>
+__global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__restrict__ xrp, const int32_t *__restrict__ xc, const double *__restrict__ xv,
+                                                const int32_t *__restrict__ yrp, const int32_t *__restrict__ yc, const double *__restrict__ yv,
+                                                int32_t *__restrict__ cnt, const int32_t *__restrict__ crp, int32_t *__restrict__ cc,
+                                                double *__restrict__ cv, int32_t *flag) {
+    __shared__ int32_t keys[4][SLOTS];
+    __shared__ int32_t list[4][SLOTS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    if (row >= nx) return;                      // no block-wide barriers below: a wave works on its own tables
+    int32_t *K = keys[wave], *L = list[wave];
+    for (int sl = lane; sl < SLOTS; sl += 64) K[sl] = INT_MAX;
+    wave_sync();
+    const int32_t xs = xrp[row], xe = xrp[row + 1];
+    bool overflow = false;
+    for (int32_t p = xs + lane; p < xe; p += 64) {
+        const int32_t k = xc[p];
+        const int32_t ye = yrp[k + 1];
+        for (int32_t q = yrp[k]; q < ye; ++q) {
+            const int32_t j = yc[q];
+            uint32_t h = ((uint32_t(j) * 2654435761u) >> 16) & (SLOTS - 1);
+            bool placed = false;
+            for (int probe = 0; probe < SLOTS; ++probe) {
+                const int32_t old = atomicCAS(&K[h], INT_MAX, j);
+                if (old == INT_MAX || old == j) { placed = true; break; }
+                h = (h + 1) & (SLOTS - 1);
+            }
+            overflow |= !placed;
+        }
+    }
+    wave_sync();
+    // compact the occupied slots into the list (any order), count them
+    int c = 0;
+    for (int base = 0; base < SLOTS; base += 64) {
+        const int32_t v = K[base + lane];
+        const bool occ = v != INT_MAX;
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(occ);
+        if (occ) L[c + __builtin_popcountll(bal & ((uint64_t(1) << lane) - 1))] = v;
+        c += __builtin_popcountll(bal);
+    }
+    if (__builtin_amdgcn_ballot_w64(overflow) != 0 || c > SLOTS / 2) {
+        if (lane == 0) atomicOr(flag, 1);
+        c = 0;
+    }
+    if (PASS == 0) {
+        if (lane == 0) cnt[row] = c;
+        return;
+    }
+    if (c == 0) return;
+    int m = 64;                                  // bitonic sort of the list padded to a power of two
+    while (m < c) m <<= 1;
+    for (int t = c + lane; t < m; t += 64) L[t] = INT_MAX;
+    wave_sync();
+    for (int size = 2; size <= m; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < m / 2; t += 64) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int32_t a = L[lo], b = L[hi];
+                if ((a > b) == up) { L[lo] = b; L[hi] = a; }
+            }
+            wave_sync();
+        }
+    const int64_t off = crp[row];
+    for (int t = lane; t < c; t += 64) {
+        const int32_t j = L[t];
+        double acc = 0.0;
+        for (int32_t p = xs; p < xe; ++p) {      // fixed order over the row of X
+            const int32_t k = xc[p];
+            const int32_t ys = yrp[k], ye = yrp[k + 1];
+            const int32_t q = lower_bound_i32(yc, ys, ye, j);
+            if (q < ye && yc[q] == j) acc += xv[p] * yv[q];
+        }
+        cc[off + t] = j;
+        cv[off + t] = acc;
+    }
+}
+
+// ---- transpose by sorting (column << 32 | row) ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose_keys(int64_t n, int rbits, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        uint64_t *__restrict__ keys) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) keys[p] = (uint64_t(uint32_t(col[p])) << rbits) | uint64_t(uint32_t(i));
+}
+
+__global__ void __launch_bounds__(256) k_transpose_finish(int64_t ncols, int64_t nnz, int rbits, const uint64_t *__restrict__ keys, int32_t *__restrict__ rp,
+                                                          int32_t *__restrict__ rc) {
+    const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t < nnz) rc[t] = int32_t(uint32_t(keys[t] & ((uint64_t(1) << rbits) - 1)));
+    if (t <= ncols) {
+        const uint64_t key = uint64_t(t) << rbits;
+        int64_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        rp[t] = int32_t(lo);
+    }
+}
+
+// ---- dense inverse of the coarsest operator: in-place Gauss-Jordan in LDS, no pivoting (symmetric positive definite) --------
+__global__ void __launch_bounds__(256) k_dense_inverse(int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       const double *__restrict__ val, double *__restrict__ inv, int32_t *flag) {
+    __shared__ double a[kAmgDenseMax * kAmgDenseMax];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) a[e] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) a[i * n + col[p]] = val[p];
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        const double piv = a[p * n + p];
+        if (!(piv > 0.0)) { if (tid == 0) atomicOr(flag, 2); return; }   // uniform: every thread reads the same entry
+        const double ip = 1.0 / piv;
+        __syncthreads();
+        for (int j = tid; j < n; j += 256)
+            if (j != p) a[p * n + j] *= ip;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            if (i != p && j != p) a[e] -= a[i * n + p] * a[p * n + j];
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256)
+            a[i * n + p] = (i == p) ? ip : -a[i * n + p] * ip;
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += 256) inv[e] = a[e];
+}
+
+template <class S, class D> __global__ void __launch_bounds__(256) k_convert(int64_t n, const S *__restrict__ src, D *__restrict__ dst) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = D(src[i]);
+}
+
+// ---- the cycle -------------------------------------------------------------------------------------------------------------
+// Row operations: 8 lanes per row split its entries, every lane carries all K columns, the transposing reduction
+// (wave_util.h) leaves column `mycol` of the row sum in lanes with `mine`.  The same device functions serve the one-launch-
+// per-operation kernels of the large levels and the single-workgroup kernel that walks all small levels (k_amg_tail).
+constexpr int kLpr = 8;
+
+template <class T, int K, bool SCALE, int LPR = kLpr>
+__device__ __forceinline__ void row_product(int32_t rs, int32_t re, int sub, const int32_t *__restrict__ col, const T *__restrict__ val,
+                                            const T *__restrict__ dinv, const T *__restrict__ x, T (&acc)[K]) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) acc[c] = T(0);
+    for (int32_t p0 = rs + sub; p0 < re; p0 += 2 * LPR) {   // two passes of loads in flight
+        int32_t j[2];
+        T a[2], xv[2][K];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int32_t p = p0 + u * LPR;
+            j[u] = -1; a[u] = T(0);
+            if (p < re) { j[u] = col[p]; a[u] = val[p]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) xv[u][c] = T(0);
+            if (j[u] >= 0) {
+                if (SCALE) a[u] *= dinv[j[u]];
+                const T *xr = x + int64_t(j[u]) * K;
+#pragma unroll
+                for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < K; ++c) acc[c] += a[u] * xv[u][c];
+    }
+    TReduce<K, LPR>::run(acc, sub);
+}
+
+struct Lane {
+    int sub, mycol;
+    bool mine;
+};
+template <int K, int LPR = kLpr> __device__ __forceinline__ Lane lane_of(int tid) {
+    int idx[K], own[K];
+    Lane l;
+    l.sub = tid % LPR;
+    towner_init<K, LPR>(idx, own, l.sub);
+    l.mycol = idx[0];
+    l.mine = own[0] != 0;
+    return l;
+}
+
+// first half on a level: z = w D^-1 r (from zero), t = r - A z
+template <class T, int K> __device__ __forceinline__ void op_pre(const AmgLevelT<T> &a, const T *__restrict__ r, int64_t row, const Lane &ln) {
+    T acc[K];
+    row_product<T, K, true>(a.rowptr[row], a.rowptr[row + 1], ln.sub, a.col, a.val, a.dinv, r, acc);
+    if (ln.mine) {
+        const int64_t at = row * K + ln.mycol;
+        const T w = T(a.omega), ri = r[at];
+        a.z[at] = w * a.dinv[row] * ri;
+        a.t[at] = ri - w * acc[0];
+    }
+}
+// r_next = R t
+template <class T, int K, int LPR = kLpr> __device__ __forceinline__ void op_restrict(const AmgLevelT<T> &a, T *__restrict__ rn, int64_t row, const Lane &ln) {
+    T acc[K];
+    row_product<T, K, false, LPR>(a.r_rowptr[row], a.r_rowptr[row + 1], ln.sub, a.r_col, a.r_val, (const T *)nullptr, (const T *)a.t, acc);
+    if (ln.mine) rn[row * K + ln.mycol] = acc[0];
+}
+// z += P z_next
+template <class T, int K> __device__ __forceinline__ void op_prolong(const AmgLevelT<T> &a, const T *__restrict__ zn, int64_t row, const Lane &ln) {
+    T acc[K];
+    row_product<T, K, false>(a.p_rowptr[row], a.p_rowptr[row + 1], ln.sub, a.p_col, a.p_val, (const T *)nullptr, zn, acc);
+    if (ln.mine) a.z[row * K + ln.mycol] += acc[0];
+}
+// second half: zout = z + w D^-1 (r - A z); LAST (finest level): zout / dinv is stored, the return value is r * zout
+template <class T, int K, bool LAST>
+__device__ __forceinline__ double op_post(const AmgLevelT<T> &a, const T *__restrict__ r, T *__restrict__ zout, int64_t row, const Lane &ln) {
+    T acc[K];
+    row_product<T, K, false>(a.rowptr[row], a.rowptr[row + 1], ln.sub, a.col, a.val, (const T *)nullptr, (const T *)a.z, acc);
+    double dot = 0.0;
+    if (ln.mine) {
+        const int64_t at = row * K + ln.mycol;
+        const T ri = r[at], di = a.dinv[row];
+        const T zn = a.z[at] + T(a.omega) * di * (ri - acc[0]);
+        zout[at] = LAST ? zn / di : zn;
+        dot = double(ri) * double(zn);
+    }
+    return dot;
+}
+
+constexpr int kRpb = 256 / kLpr;   // rows per workgroup of the one-operation kernels
+
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_amg_pre(AmgLevelT<T> a, const T *__restrict__ r, const double *scal, int step) {
+    if (amg_done(scal, step)) return;
+    const Lane ln = lane_of<K>(threadIdx.x);
+    const int64_t row = int64_t(blockIdx.x) * kRpb + threadIdx.x / kLpr;
+    if (row < a.n) op_pre<T, K>(a, r, row, ln);
+}
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_amg_restrict(AmgLevelT<T> a, int64_t n_next, T *__restrict__ rn, const double *scal, int step) {
+    if (amg_done(scal, step)) return;
+    const Lane ln = lane_of<K>(threadIdx.x);
+    const int64_t row = int64_t(blockIdx.x) * kRpb + threadIdx.x / kLpr;
+    if (row < n_next) op_restrict<T, K>(a, rn, row, ln);
+}
+template <class T, int K>
+__global__ void __launch_bounds__(256) k_amg_prolong(AmgLevelT<T> a, const T *__restrict__ zn, const double *scal, int step) {
+    if (amg_done(scal, step)) return;
+    const Lane ln = lane_of<K>(threadIdx.x);
+    const int64_t row = int64_t(blockIdx.x) * kRpb + threadIdx.x / kLpr;
+    if (row < a.n) op_prolong<T, K>(a, zn, row, ln);
+}
+// (prolongation folded into this sweep - P z_next formed on the fly for the row and its neighbours - was measured: 24.7 us
+// against 5.3 + 12 at 80 k rows, the inner loops over P's rows are chains of dependent loads)
+template <class T, int K, bool LAST, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_amg_post(AmgLevelT<T> a, const T *__restrict__ r, T *__restrict__ zout,
+                                                     double *__restrict__ part, const double *scal, int step) {
+    if (amg_done(scal, step)) return;
+    const Lane ln = lane_of<K>(threadIdx.x);
+    constexpr int RPB = THREADS / kLpr;
+    double dot = 0.0;
+    for (int64_t row = int64_t(blockIdx.x) * RPB + threadIdx.x / kLpr; row < a.n; row += int64_t(gridDim.x) * RPB)
+        dot += op_post<T, K, LAST>(a, r, zout, row, ln);
+    if (LAST) {   // <r, z> partials of the workgroup, one per column
+        constexpr int NW = THREADS / 64;
+        __shared__ double smem[NW * K];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double x = wave_sum((ln.mine && k == ln.mycol) ? dot : 0.0);
+            if (lane == 0) smem[wave * K + k] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x < K) {
+            double t = 0.0;
+            for (int w = 0; w < NW; ++w) t += smem[w * K + threadIdx.x];
+            part[blockIdx.x * K + threadIdx.x] = t;
+        }
+    }
+}
+
+template <class T, int K>
+__device__ __forceinline__ void op_dense(int n, const T *__restrict__ inv, const T *__restrict__ r, T *__restrict__ z, int t) {
+    const int row = t / K, c = t - row * K;
+    T acc = T(0);
+    for (int j = 0; j < n; ++j) acc += inv[j * n + row] * r[j * K + c];   // the inverse is symmetric: column = row, coalesced
+    z[t] = acc;
+}
+
+// all small levels in ONE workgroup: pre / restrict down to the dense coarsest solve, prolong / post back up; the barriers of
+// the workgroup stand in for the kernel boundaries (every vector goes through the L2, one CU, one L1)
+constexpr int kTailLevels = 3;
+constexpr int kTailRows = 128;     // levels of at most this many rows go into the tail kernel (the coarsest one always)
+template <class T> struct AmgTailT {
+    int levels;
+    AmgLevelT<T> up;               // the level above the tail: its R and t feed the first restriction (16 lanes per row: R's rows are long)
+    AmgLevelT<T> lev[kTailLevels];
+    const T *inv;
+};
+template <class T, int K>
+__global__ void __launch_bounds__(1024) k_amg_tail(AmgTailT<T> A, const double *scal, int step) {
+    if (amg_done(scal, step)) return;
+    const Lane ln = lane_of<K>(threadIdx.x);
+    const int g = threadIdx.x / kLpr, ng = 1024 / kLpr;
+    const int L = A.levels;
+    {
+        const Lane l16 = lane_of<K, 16>(threadIdx.x);
+        for (int64_t row = threadIdx.x / 16; row < A.lev[0].n; row += 1024 / 16) op_restrict<T, K, 16>(A.up, A.lev[0].r, row, l16);
+        __syncthreads();
+    }
+    for (int l = 0; l + 1 < L; ++l) {
+        const AmgLevelT<T> &a = A.lev[l];
+        for (int64_t row = g; row < a.n; row += ng) op_pre<T, K>(a, (const T *)a.r, row, ln);
+        __syncthreads();
+        const AmgLevelT<T> &b = A.lev[l + 1];
+        for (int64_t row = g; row < b.n; row += ng) op_restrict<T, K>(a, b.r, row, ln);
+        __syncthreads();
+    }
+    {
+        const AmgLevelT<T> &c = A.lev[L - 1];
+        for (int t = threadIdx.x; t < int(c.n) * K; t += 1024) op_dense<T, K>(int(c.n), A.inv, (const T *)c.r, c.z2, t);
+        __syncthreads();
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        const AmgLevelT<T> &a = A.lev[l];
+        const AmgLevelT<T> &b = A.lev[l + 1];
+        for (int64_t row = g; row < a.n; row += ng) op_prolong<T, K>(a, (const T *)b.z2, row, ln);
+        __syncthreads();
+        for (int64_t row = g; row < a.n; row += ng) (void)op_post<T, K, false>(a, (const T *)a.r, a.z2, row, ln);
+        __syncthreads();
+    }
+}
+
+int grid_rows(int64_t n, int per_block) { return int((n + per_block - 1) / per_block); }
+
+// out[0 .. n] = exclusive prefix sums of cnt[0 .. n) (out[n] = total; cnt[n] must be addressable, its value does not matter);
+// the temporary storage comes from the scratch end of the arena and is released by the caller's mark
+void scan_counts(Arena &ar, hipStream_t s, int64_t n, const int32_t *cnt, int32_t *out) {
+    size_t tb = 0;
+    HIP_OK(rocprim::exclusive_scan(nullptr, tb, cnt, out, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s));
+    void *tmp = ar.hi<char>(tb + 256);
+    HIP_OK(rocprim::exclusive_scan(tmp, tb, cnt, out, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s));
+}
+
+// one product C = X Y into arena memory: count, scan, (sync: size), fill.  Returns nnz(C); -1 when a row overflowed.
+struct Csr {
+    int64_t n = 0, nnz = 0;
+    int32_t *rowptr = nullptr, *col = nullptr;
+    double *val = nullptr;
+};
+
+int64_t spgemm(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const Csr &Y, int32_t *d_flag, Csr &C) {
+    C.n = X.n;
+    C.rowptr = permanent ? ar.lo<int32_t>(size_t(X.n) + 2) : ar.hi<int32_t>(size_t(X.n) + 2);
+    const int g = grid_rows(X.n, 4);
+    int32_t *d_over = d_flag + 40;   // overflow of the product's hash tables, apart from the setup's other flags
+    for (int slots = 128; slots <= 512; slots *= 4) {
+        const size_t mark = ar.hi_mark();
+        int32_t *cnt = ar.hi<int32_t>(size_t(X.n) + 2);
+        HIP_OK(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
+        if (slots == 128)
+            hipLaunchKernelGGL((k_spgemm<0, 128>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, (const int32_t *)nullptr,
+                               (int32_t *)nullptr, (double *)nullptr, d_over);
+        else
+            hipLaunchKernelGGL((k_spgemm<0, 512>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, (const int32_t *)nullptr,
+                               (int32_t *)nullptr, (double *)nullptr, d_over);
+        scan_counts(ar, s, X.n, cnt, C.rowptr);
+        int32_t h[2] = {0, 0};
+        HIP_OK(hipMemcpyAsync(&h[0], C.rowptr + X.n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&h[1], d_over, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        ar.hi_release(mark);
+        if (h[1] != 0) {
+            if (slots == 512) return -1;
+            continue;
+        }
+        if (h[0] <= 0 || h[0] == INT_MAX) return -1;
+        C.nnz = h[0];
+        C.col = permanent ? ar.lo<int32_t>(size_t(C.nnz) + 2) : ar.hi<int32_t>(size_t(C.nnz) + 2);
+        C.val = permanent ? ar.lo<double>(size_t(C.nnz) + 2) : ar.hi<double>(size_t(C.nnz) + 2);
+        if (slots == 128)
+            hipLaunchKernelGGL((k_spgemm<1, 128>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, (int32_t *)nullptr,
+                               (const int32_t *)C.rowptr, C.col, C.val, d_over);
+        else
+            hipLaunchKernelGGL((k_spgemm<1, 512>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, (int32_t *)nullptr,
+                               (const int32_t *)C.rowptr, C.col, C.val, d_over);
+        return C.nnz;
+    }
+    return -1;
+}
+
+}  // namespace
+
+bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax, AmgT<double> &H,
+               std::string &why) {
+    H = AmgT<double>{};
+    if (nv <= kAmgDenseMax) { why = "vertex block too small"; return false; }
+    const size_t hi0 = ar.hi_mark();
+    try {
+        int32_t *d_flag = ar.lo<int32_t>(64);               // [0] flags, [1 ..] undecided counters
+        unsigned long long *d_bound = ar.lo<unsigned long long>(kAmgMaxLevels + 1);
+        HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int32_t) * 64, s));
+        HIP_OK(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long) * (kAmgMaxLevels + 1), s));
+        // level 0: compact copy of the leading block
+        Csr A;
+        A.n = nv;
+        A.rowptr = ar.lo<int32_t>(size_t(nv) + 2);
+        {
+            const size_t mark = ar.hi_mark();
+            int32_t *cnt = ar.hi<int32_t>(size_t(nv) + 2);
+            hipLaunchKernelGGL((k_block_copy<0>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, cnt, (const int32_t *)nullptr,
+                               (int32_t *)nullptr, (double *)nullptr);
+            scan_counts(ar, s, nv, cnt, A.rowptr);
+            int32_t h = 0;
+            HIP_OK(hipMemcpyAsync(&h, A.rowptr + nv, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            ar.hi_release(mark);
+            if (h <= 0 || h == INT_MAX) { why = "empty vertex block"; return false; }
+            A.nnz = h;
+            A.col = ar.lo<int32_t>(size_t(h) + 2);
+            A.val = ar.lo<double>(size_t(h) + 2);
+            hipLaunchKernelGGL((k_block_copy<1>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, (int32_t *)nullptr,
+                               (const int32_t *)A.rowptr, A.col, A.val);
+        }
+        int L = 0;
+        for (;;) {
+            AmgLevelT<double> &lv = H.lev[L];
+            const int64_t n = A.n;
+            lv.n = n; lv.nnz = A.nnz; lv.rowptr = A.rowptr; lv.col = A.col; lv.val = A.val;
+            double *dinv = ar.lo<double>(size_t(n) + 2);
+            lv.dinv = dinv;
+            lv.z = ar.lo<double>(size_t(n) * kmax + 2);
+            lv.z2 = ar.lo<double>(size_t(n) * kmax + 2);
+            lv.t = ar.lo<double>(size_t(n) * kmax + 2);
+            if (L > 0) lv.r = ar.lo<double>(size_t(n) * kmax + 2);
+            const int g = grid_rows(n, 256);
+            hipLaunchKernelGGL(k_level_diag, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, d_bound + L, d_flag);
+            if (n <= kAmgDenseMax) {   // coarsest: dense inverse
+                double *inv = ar.lo<double>(size_t(n) * n + 2);
+                hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(256), 0, s, int(n), A.rowptr, A.col, A.val, inv, d_flag);
+                H.inv = inv;
+                H.levels = L + 1;
+                break;
+            }
+            if (L + 1 >= kAmgMaxLevels) { why = "too many levels"; ar.hi_release(hi0); return false; }
+            // ---- aggregation ----
+            const size_t mark = ar.hi_mark();
+            uint64_t *tup = ar.hi<uint64_t>(size_t(n) + 2), *m1 = ar.hi<uint64_t>(size_t(n) + 2);
+            int32_t *isroot = ar.hi<int32_t>(size_t(n) + 2), *id = ar.hi<int32_t>(size_t(n) + 2);
+            int32_t *agg1 = ar.hi<int32_t>(size_t(n) + 2), *agg = ar.hi<int32_t>(size_t(n) + 2);
+            hipLaunchKernelGGL(k_mis_init, dim3(g), dim3(256), 0, s, n, tup);
+            int32_t h_left = 1;
+            int rounds = 0;
+            unsigned long long h_bound = 0;
+            int32_t h_flag = 0;
+            while (h_left > 0) {
+                if (++rounds > 8) { why = "aggregation did not settle"; ar.hi_release(hi0); return false; }
+                int32_t *d_left = d_flag + 1 + (rounds & 31);
+                for (int it = 0; it < 6; ++it) {
+                    hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
+                    if (it == 5) HIP_OK(hipMemsetAsync(d_left, 0, sizeof(int32_t), s));
+                    hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1, d_left);
+                }
+                HIP_OK(hipMemcpyAsync(&h_left, d_left, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(&h_bound, d_bound + L, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_OK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_OK(hipStreamSynchronize(s));
+            }
+            double lmax;
+            std::memcpy(&lmax, &h_bound, sizeof lmax);
+            if (h_flag != 0 || !(lmax > 0.0) || !std::isfinite(lmax)) { why = "level operator without a positive diagonal"; ar.hi_release(hi0); return false; }
+            lv.omega = 1.6 / lmax;
+            hipLaunchKernelGGL(k_mis_flags, dim3(g), dim3(256), 0, s, n, tup, isroot);
+            scan_counts(ar, s, n, isroot, id);
+            hipLaunchKernelGGL(k_agg_near, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, id, agg1);
+            hipLaunchKernelGGL(k_agg_far, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, agg1, agg);
+            int32_t h_nc = 0;
+            HIP_OK(hipMemcpyAsync(&h_nc, id + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            // ---- P = (I - 4/(3 lmax) D^-1 A) P0 ----
+            Csr S = A, P0;
+            S.val = ar.hi<double>(size_t(A.nnz) + 2);
+            P0.n = n; P0.nnz = n;
+            P0.rowptr = ar.hi<int32_t>(size_t(n) + 2); P0.col = ar.hi<int32_t>(size_t(n) + 2); P0.val = ar.hi<double>(size_t(n) + 2);
+            hipLaunchKernelGGL(k_smoothing_factor, dim3(grid_rows(n + 1, 256)), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, 4.0 / (3.0 * lmax), S.val,
+                               agg, P0.rowptr, P0.col, P0.val);
+            HIP_OK(hipStreamSynchronize(s));
+            const int64_t nc = h_nc;
+            if (nc <= 0 || nc * 10 > n * 8) { why = "no coarsening"; ar.hi_release(hi0); return false; }
+            Csr P;
+            if (spgemm(ar, true, s, S, P0, d_flag, P) < 0) { why = "prolongator row too long"; ar.hi_release(hi0); return false; }
+            lv.p_rowptr = P.rowptr; lv.p_col = P.col; lv.p_val = P.val; lv.nnz_p = P.nnz;
+            // ---- R = P^T ----
+            Csr R;
+            R.n = nc; R.nnz = P.nnz;
+            R.rowptr = ar.lo<int32_t>(size_t(nc) + 2); R.col = ar.lo<int32_t>(size_t(P.nnz) + 2); R.val = ar.lo<double>(size_t(P.nnz) + 2);
+            {
+                uint64_t *k_in = ar.hi<uint64_t>(size_t(P.nnz) + 2), *k_out = ar.hi<uint64_t>(size_t(P.nnz) + 2);
+                int rbits = 1, cbits = 1;   // key = column << rbits | row: only the bits in use take part in the sort
+                while ((int64_t(1) << rbits) < n) ++rbits;
+                while ((int64_t(1) << cbits) < nc + 1) ++cbits;
+                hipLaunchKernelGGL(k_transpose_keys, dim3(g), dim3(256), 0, s, n, rbits, P.rowptr, P.col, k_in);
+                size_t tb = 0;
+                HIP_OK(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, P.val, R.val, size_t(P.nnz), 0u, unsigned(rbits + cbits), s));
+                void *tmp = ar.hi<char>(tb + 256);
+                HIP_OK(rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, P.val, R.val, size_t(P.nnz), 0u, unsigned(rbits + cbits), s));
+                const int64_t span = P.nnz > nc + 1 ? P.nnz : nc + 1;
+                hipLaunchKernelGGL(k_transpose_finish, dim3(grid_rows(span, 256)), dim3(256), 0, s, nc, P.nnz, rbits, k_out, R.rowptr, R.col);
+            }
+            lv.r_rowptr = R.rowptr; lv.r_col = R.col; lv.r_val = R.val;
+            // ---- A' = R (A P) ----
+            Csr AP, Ac;
+            if (spgemm(ar, false, s, A, P, d_flag, AP) < 0) { why = "A P row too long"; ar.hi_release(hi0); return false; }
+            if (spgemm(ar, true, s, R, AP, d_flag, Ac) < 0) { why = "coarse row too long"; ar.hi_release(hi0); return false; }
+            HIP_OK(hipStreamSynchronize(s));   // the scratch of this level is released next
+            ar.hi_release(mark);
+            A = Ac;
+            A.n = nc;
+            ++L;
+        }
+        int32_t h_flag = 0;
+        HIP_OK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        ar.hi_release(hi0);
+        if (h_flag != 0) { why = "coarsest operator not positive definite"; return false; }
+        H.launches = 4 * (H.levels - 1) + 1;
+        return true;
+    } catch (const std::exception &ex) {
+        ar.hi_release(hi0);
+        why = ex.what();
+        return false;
+    }
+}
+
+void amg_to_float(Arena &ar, hipStream_t s, const AmgT<double> &in, int kmax, AmgT<float> &out) {
+    auto conv = [&](const double *src, size_t count) {
+        float *dst = ar.lo<float>(count + 4);
+        hipLaunchKernelGGL((k_convert<double, float>), dim3(grid_rows(int64_t(count), 256)), dim3(256), 0, s, int64_t(count), src, dst);
+        return (const float *)dst;
+    };
+    out = AmgT<float>{};
+    out.levels = in.levels;
+    out.launches = in.launches;
+    for (int l = 0; l < in.levels; ++l) {
+        const AmgLevelT<double> &a = in.lev[l];
+        AmgLevelT<float> &b = out.lev[l];
+        b.n = a.n; b.nnz = a.nnz; b.rowptr = a.rowptr; b.col = a.col; b.omega = a.omega;
+        b.val = conv(a.val, size_t(a.nnz));
+        b.dinv = conv(a.dinv, size_t(a.n));
+        b.z = ar.lo<float>(size_t(a.n) * kmax + 4); b.z2 = ar.lo<float>(size_t(a.n) * kmax + 4); b.t = ar.lo<float>(size_t(a.n) * kmax + 4);
+        if (l > 0) b.r = ar.lo<float>(size_t(a.n) * kmax + 4);
+        if (l + 1 < in.levels) {
+            b.p_rowptr = a.p_rowptr; b.p_col = a.p_col; b.r_rowptr = a.r_rowptr; b.r_col = a.r_col;
+            b.nnz_p = a.nnz_p;
+            b.p_val = conv(a.p_val, size_t(a.nnz_p));
+            b.r_val = conv(a.r_val, size_t(a.nnz_p));
+        }
+    }
+    const int64_t nc = in.lev[in.levels - 1].n;
+    out.inv = conv(in.inv, size_t(nc * nc));
+}
+
+template <class T> void launch_amg_cycle(const AmgT<T> &H, int k, int step, const T *r, T *cz, double *part, int nblocks, const double *scal, hipStream_t s) {
+    const int L = H.levels;
+#define AMG_K_SWITCH(CALL)                                  \
+    switch (k) {                                            \
+        case 1: { constexpr int KK = 1; CALL; } break;      \
+        case 2: { constexpr int KK = 2; CALL; } break;      \
+        case 3: { constexpr int KK = 3; CALL; } break;      \
+        case 4: { constexpr int KK = 4; CALL; } break;      \
+        case 5: { constexpr int KK = 5; CALL; } break;      \
+        case 6: { constexpr int KK = 6; CALL; } break;      \
+        case 7: { constexpr int KK = 7; CALL; } break;      \
+        default: { constexpr int KK = 8; CALL; } break;     \
+    }
+    auto rows_grid = [&](int64_t n) { return int((n + kRpb - 1) / kRpb); };
+    // the levels from `lt` on go into the single-workgroup kernel (always at least the coarsest one)
+    int lt = L - 1;
+    while (lt > 1 && H.lev[lt - 1].n <= kTailRows && L - (lt - 1) <= kTailLevels) --lt;
+    for (int l = 0; l < lt; ++l) {   // down
+        const AmgLevelT<T> &a = H.lev[l], &b = H.lev[l + 1];
+        const T *rl = (l == 0) ? r : (const T *)a.r;
+        AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_pre<T, KK>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, rl, scal, step));
+        if (l + 1 < lt) AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_restrict<T, KK>), dim3(rows_grid(b.n)), dim3(256), 0, s, a, b.n, b.r, scal, step));
+    }
+    {
+        AmgTailT<T> tail;
+        tail.levels = L - lt;
+        tail.up = H.lev[lt - 1];
+        for (int l = lt; l < L; ++l) tail.lev[l - lt] = H.lev[l];
+        tail.inv = H.inv;
+        AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_tail<T, KK>), dim3(1), dim3(1024), 0, s, tail, scal, step));
+    }
+    for (int l = lt - 1; l >= 0; --l) {   // up
+        const AmgLevelT<T> &a = H.lev[l], &b = H.lev[l + 1];
+        const T *rl = (l == 0) ? r : (const T *)a.r;
+        AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_prolong<T, KK>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, (const T *)b.z2, scal, step));
+        if (l == 0) {   // the launch that leaves the partial sums is held to `nblocks` workgroups: 128 rows each
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, true, 1024>), dim3(nblocks), dim3(1024), 0, s, a, rl, cz, part, scal, step));
+        } else {
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, false, 256>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, rl, a.z2, (double *)nullptr, scal, step));
+        }
+    }
+#undef AMG_K_SWITCH
+}
+
+template void launch_amg_cycle<double>(const AmgT<double> &, int, int, const double *, double *, double *, int, const double *, hipStream_t);
+template void launch_amg_cycle<float>(const AmgT<float> &, int, int, const float *, float *, double *, int, const double *, hipStream_t);
+
+}  // namespace remo

@@ -18,6 +18,8 @@ struct PcgProgress {
 
 // T = storage type of matrix values and vectors: double (product path) or float (inner solver of the
 // mixed-precision mode); scalars and partial sums are double in both
+template <class T> struct AmgT;   // amg.h
+
 template <class T> struct PcgBuffersT {
     T *x, *r, *p, *q;       // [n*k]
     const T *dinv;          // [n]
@@ -44,12 +46,15 @@ template <class T> struct PcgBuffersT {
     // vertex rows' Jacobi factors, chain vectors [nv_coarse * k]
     const float *c32_val = nullptr, *c32_dinv = nullptr;
     float *c32_z = nullptr, *c32_res = nullptr, *c32_d[2] = {nullptr, nullptr};
+    // multigrid cycle on the vertex block instead of the polynomial (amg.h; 2D by default); nullptr -> Chebyshev
+    const AmgT<T> *amg = nullptr;
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
 };
 using PcgBuffers = PcgBuffersT<double>;
 constexpr int kScalarSlots = 48;   // doubles behind PcgBuffersT::rz0
+constexpr int kDoneSlot = 4 * 8;   // rz0[kDoneSlot] (as int): step + 1 of the update launch that froze every column (kernels.hip solve_done)
 
 // Element-wise operator (3D, remo_opts_t.op = 1): everything y = A x needs instead of the stored matrix
 template <class T> struct ElemOpT {

@@ -6,100 +6,14 @@
 // coalesced CSR streams, DPP (not LDS) cross-lane reductions, XCD-aware row placement, LDS-staged reference
 // tensors and few launches per PCG step.  Reference lines each kernel replaces are cited at the kernel.
 #include "kernels.h"
+#include "amg.h"
 
 #include <limits.h>
 
 #include "fem_p3.h"
+#include "wave_util.h"
 
 namespace remo {
-
-// ------------------------------------------------------------------------------------------
-// wave / block reductions (wave = 64 lanes)
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-template <int W, class T> __device__ __forceinline__ T group_sum(T v) {
-#pragma unroll
-    for (int off = W / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// ---- transposing reduction ---------------------------------------------------------------
-// A group of W lanes holds M partial values per lane and needs the M group sums.  Summing each value
-// with its own butterfly costs M log2(W) lane exchanges, and on gfx9 a __shfl is a ds_bpermute through
-// the LDS pipe that all four SIMDs share: for the SpMM (M = 10 values per edge-row pair) that pipe,
-// not HBM, set the kernel time.  Here every exchange step HALVES the value list instead: the two
-// halves of the group keep one value of each pair and send the other, so the whole reduction costs
-// M - 1 + (odd leftovers) exchanges, all of them DPP moves inside a 16-lane row (VALU, no LDS), and
-// ends with the sums spread over the lanes, one (or ceil(M / W)) per lane, which also turns the M
-// serial stores of lane 0 into one coalesced store.
-template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-// value of the partner lane in the other half of the W-lane group (a bijection between the halves)
-template <int W, class T> __device__ __forceinline__ T partner(T v) {
-    if constexpr (W == 16) return dpp_mov<0x140>(v);      // row_mirror: i <-> 15 - i
-    else if constexpr (W == 8) return dpp_mov<0x141>(v);  // row_half_mirror: i <-> 7 - i
-    else if constexpr (W == 4) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    else if constexpr (W == 2) return dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-    else return __shfl_xor(v, W / 2, 64);
-}
-constexpr int treduce_out(int m, int w) { return w < 2 ? m : treduce_out((m + 1) / 2, w / 2); }
-// In place: on return v[0 .. treduce_out(M, W)) are complete group sums; which ones, per lane, is
-// given by TOwner below (same recursion on indices).  Fixed order: deterministic.
-template <int M, int W> struct TReduce {
-    template <class T> static __device__ __forceinline__ void run(T *v, int sub) {
-        if constexpr (W >= 2) {
-            const bool hi = (sub & (W / 2)) != 0;
-            constexpr int P = M / 2;
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const T a = v[2 * j], b = v[2 * j + 1];
-                v[j] = (hi ? b : a) + partner<W, T>(hi ? a : b);
-            }
-            if constexpr (M & 1) {
-                const T l = v[M - 1];
-                v[P] = l + partner<W, T>(l);
-            }
-            TReduce<(M + 1) / 2, W / 2>::run(v, sub);
-        }
-    }
-};
-// idx[f] = index (0 .. M-1) of the original value whose sum lane `sub` holds in v[f] after TReduce;
-// an odd leftover is carried by both halves, and only the lane that took the low half every time it
-// was carried is its owner (own[f]), so that each sum is stored exactly once.
-template <int M, int W> struct TOwner {
-    static __device__ __forceinline__ void run(int *idx, int *own, int sub) {
-        if constexpr (W >= 2) {
-            const int hi = (sub & (W / 2)) != 0;   // arithmetic blends: keeps the arrays in registers
-            constexpr int P = M / 2;
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                idx[j] = idx[2 * j] + hi * (idx[2 * j + 1] - idx[2 * j]);
-                own[j] = own[2 * j] + hi * (own[2 * j + 1] - own[2 * j]);
-            }
-            if constexpr (M & 1) {
-                idx[P] = idx[M - 1];
-                own[P] = own[M - 1] * (1 - hi);
-            }
-            TOwner<(M + 1) / 2, W / 2>::run(idx, own, sub);
-        }
-    }
-};
-template <int M, int W> __device__ __forceinline__ void towner_init(int (&idx)[M], int (&own)[M], int sub) {
-#pragma unroll
-    for (int j = 0; j < M; ++j) { idx[j] = j; own[j] = 1; }
-    TOwner<M, W>::run(idx, own, sub);
-}
 
 // Sum K per-thread values over the block (blockDim.x multiple of 64, <= 1024).  Result valid in
 // every thread.  Deterministic: fixed tree.
@@ -186,7 +100,6 @@ __device__ __forceinline__ int64_t value_pos(int64_t row, int32_t rs, int32_t le
 // launches of step s itself (the update that raises the flag included) never act on it: a workgroup whose waves start
 // on both sides of the store would otherwise split, the early leavers missing from the block sums of the rest.  They
 // run a harmless step instead (alpha = beta = 0 for every column).
-constexpr int kDoneSlot = 4 * 8;
 __device__ __forceinline__ bool solve_done(const double *scal, int step) {
     const int d = reinterpret_cast<const int *>(scal + kDoneSlot)[0];
     return d != 0 && d <= step;
@@ -1586,11 +1499,15 @@ template <class T> static ChebArgsT<T> cheb_args(const PcgBuffersT<T> &b) {
 template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b) {
     // measured in the bench, fold on vs off on one box: -2.3 % solve time at 12.8 k vertices, -0.9 % at 27 k, +0.4 % at 83 k
     // (there the step is real work, not launch latency): small vertex blocks only
-    return g_fold_first && b.cheb_degree >= 3 && b.nv_coarse > 0 && b.nv_coarse <= 32768 && !(b.sq_rowptr && (b.cheb_degree & 1) == 0);
+    return g_fold_first && !b.amg && b.cheb_degree >= 3 && b.nv_coarse > 0 && b.nv_coarse <= 32768 && !(b.sq_rowptr && (b.cheb_degree & 1) == 0);
 }
 
 template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s, bool first_done = false) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
+    if (b.amg) {   // multigrid cycle instead of the polynomial (amg.hip)
+        launch_amg_cycle(*b.amg, k, step, (const T *)b.r, b.cz, part_slot + int64_t(b.nb_vec) * k, cheb_grid(b.nv_coarse), (const double *)b.rz0, s);
+        return;
+    }
     if (b.sq_rowptr && (b.cheb_degree & 1) == 0) {   // two Richardson factors of the Chebyshev polynomial per launch
         const double theta = 0.5 * (b.cheb_lmax + b.cheb_lmin), delta = 0.5 * (b.cheb_lmax - b.cheb_lmin);
         const int m = b.cheb_degree, np = m / 2;

@@ -21,6 +21,7 @@
 #include "../../include/remo3d_hip.h"
 #include "fem_p3.h"
 #include "kernels.h"
+#include "amg.h"
 #include "symbolic.h"
 #include "symbolic_gpu.h"
 
@@ -109,6 +110,8 @@ struct remo_batch {
     double *d_f = nullptr;                  // load vectors [n][k_last] of the last chunk
     ElemOpT<double> elem64{};               // element-wise operator of the last run (remo_opts_t.op = 1), pointers into the arena
     ElemOpT<float> elem32{};
+    AmgT<double> amg64{};                   // multigrid hierarchy of the vertex block of the last run (arena)
+    AmgT<float> amg32{};
     int k_last = 0;
     uint64_t run_id = 0;
     std::vector<double> u_out;
@@ -135,6 +138,7 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
+int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
@@ -346,6 +350,7 @@ void remo_opts_default(remo_opts_t *o) {
     o->time_kernels = 0;
     o->coarse_degree = 0;   // 0 = by dimension and size (remo_batch_run): e.g. Chebyshev(5) on [lmax/90, lmax] at 1e4 vertices in 3D
     o->coarse_ratio = 0;
+    o->coarse = 0;          // by dimension: multigrid cycle on the vertex block in 2D, Chebyshev polynomial in 3D
 }
 
 remo_ctx_t *remo_ctx_create(int device_id) {
@@ -510,6 +515,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
         need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
+        const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2));
+        if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * (o.precision == 1 ? 2 : 1) + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;
         if (o.precision == 1)
@@ -608,7 +615,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         int32_t h_vb[2] = {1, 0};   // flag, entries
         int32_t *vb_rowptr = nullptr, *vb_col = nullptr;
         double *vb_val = nullptr;
-        const bool want_square = two_level && (buf.cheb_degree % 2 == 0) && ((g_square == 1 && dim == 2) || g_square == 2);
+        const bool want_square = two_level && !want_amg && (buf.cheb_degree % 2 == 0) && ((g_square == 1 && dim == 2) || g_square == 2);
         // measured in the bench (--tune 13=0 against 13=1, one box): 538.9 -> 516.1 ms solve per step at 83 k vertices; at 12.8 k the
         // launches are latency, not bytes (714 -> 710 ms) and building the copy costs what it saves: larger blocks only (2 forces it)
         const bool want_compact = two_level && !want_square && (g_compact == 2 || (g_compact == 1 && buf.nv_coarse > 16384));
@@ -652,6 +659,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             buf.c32_z = ctx->take<float>(nc); buf.c32_res = ctx->take<float>(nc);
             buf.c32_d[0] = ctx->take<float>(nc); buf.c32_d[1] = ctx->take<float>(nc);
         }
+        if (two_level && want_amg) {   // multigrid cycle on the vertex block instead of the polynomial (amg.hip)
+            std::string why;
+            if (amg_setup(ctx->ar, s, buf.nv_coarse, sy.rowptr, sy.col, d_val, kmax, b->amg64, why)) buf.amg = &b->amg64;
+            else if (o.coarse == 2 || g_amg == 2) return fail(ctx, REMO_ERR_NUMERIC, "multigrid hierarchy of the vertex block: " + why);
+        }
+        st->coarse_used = !two_level ? 0 : (buf.amg ? 2 : 1);
         if (two_level) {
             double lmax;
             std::memcpy(&lmax, &h_bound, sizeof lmax);
@@ -719,6 +732,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             f.cd[0] = ctx->take<float>(nc); f.cd[1] = ctx->take<float>(nc);
             f.progress = buf.progress; f.progress_len = buf.progress_len;
             f.nb_spmv = buf.nb_spmv; f.nb_vec = buf.nb_vec;
+            if (buf.amg) {
+                amg_to_float(ctx->ar, s, b->amg64, kmax, b->amg32);
+                f.amg = &b->amg32;
+            }
             if (buf.vb_rowptr) {
                 float *vb32 = ctx->take<float>(size_t(h_vb[1]) + 1);
                 launch_to_float(h_vb[1], buf.vb_val, vb32, s);
@@ -953,6 +970,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;
+    else if (key == 16) g_amg = value;
     else set_spmm_tuning(key, value);
 }
 

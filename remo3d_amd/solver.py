@@ -25,7 +25,7 @@ class RemoError(RuntimeError):
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
               time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0,
-              serialize_solves=False, op="auto") -> RemoOpts:
+              serialize_solves=False, op="auto", coarse="auto") -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
     precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
     (BASELINE config 5); inner_digits: decimal digits of <Cr,r> between two residual replacements (0 = library default 3)."""
@@ -50,6 +50,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     if op not in ("auto", "csr", "element"):
         raise ValueError("op must be 'auto' (by size), 'csr' (SpMM on the assembled matrix) or 'element' (element-wise operator, 3D)")
     o.op = {"auto": 0, "element": 1, "csr": 2}[op]
+    if coarse not in ("auto", "chebyshev", "amg"):
+        raise ValueError("coarse must be 'auto' (multigrid cycle in 2D, Chebyshev polynomial in 3D), 'chebyshev' or 'amg'")
+    o.coarse = {"auto": 0, "chebyshev": 1, "amg": 2}[coarse]   # solver of the P1 block inside "multigrid"
     return o
 
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/remo3d_hip.h but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert L.remo_abi_version() == 3
+    assert L.remo_abi_version() == 4
 
 
 def test_options_defaults_follow_reference():

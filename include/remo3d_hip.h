@@ -86,7 +86,7 @@ typedef struct {
                                1 = Chebyshev polynomial (coarse_degree, coarse_ratio);
                                2 = one V(1,1) cycle of a smoothed-aggregation multigrid hierarchy built per batch on the device
                                    (distance-2 independent-set aggregates, Galerkin products, dense coarsest solve);
-                               0 = by dimension (default): the cycle in 2D (graded axisymmetric meshes: 40 % fewer PCG steps than
+                               0 = by dimension (default; a coarse_degree > 0 selects the polynomial): the cycle in 2D (graded axisymmetric meshes: 40 % fewer PCG steps than
                                    the polynomial of degree 28 at a quarter of its launches), the polynomial in 3D (there it is
                                    within 15 % of an exact vertex solve at degree 5-13 and the cycle gains nothing).
                                If the hierarchy cannot be built (a vertex of extreme valence) 0 falls back to the polynomial, 2 fails */

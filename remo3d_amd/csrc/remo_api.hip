@@ -515,7 +515,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
         need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
-        const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2));
+        const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2 && o.coarse_degree <= 0));   // an explicit degree asks for the polynomial
         if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * (o.precision == 1 ? 2 : 1) + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;

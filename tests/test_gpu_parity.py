@@ -311,8 +311,8 @@ def test_paired_chebyshev_steps_are_the_same_preconditioner(which, mesh2d, mesh3
     try:
         for mode in (0, 2):
             L.remo_debug_tune(6, mode)
-            outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10))
-            assert rc == 0
+            outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, coarse="chebyshev"))
+            assert rc == 0 and st["coarse_used"] == 1
             got[mode] = (np.concatenate(outs), st["iterations"][:3])
     finally:
         L.remo_debug_tune(6, 1)
@@ -539,3 +539,72 @@ def test_fp32_chebyshev_chain_inside_the_fp64_solve(mesh3d, gpu_ctx):
     finally:
         L.remo_debug_tune(9, 1); L.remo_debug_tune(13, 1); L.remo_debug_tune(15, 1)
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["2d", "3d"])
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_multigrid_cycle_on_the_vertex_block(which, precision, mesh2d, mesh3d, gpu_ctx):
+    """remo_opts_t.coarse: the smoothed-aggregation V(1,1) cycle (amg.hip) and the Chebyshev polynomial are two solvers of the
+    same P1 block inside the same two-level preconditioner: potentials agree with the oracle to 1e-8 either way, the run reports
+    which one it used, the default is the cycle in 2D and the polynomial in 3D, and an explicit degree selects the polynomial."""
+    from remo3d_amd import solver
+    mesh = mesh2d if which == "2d" else mesh3d
+    o, ref = _oracle_solve(mesh, SIGMA3, True)
+    steps = {}
+    for coarse, used in (("chebyshev", 1), ("amg", 2), ("auto", 2 if which == "2d" else 1)):
+        outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-12, maxsteps=20000, precision=precision, coarse=coarse))
+        assert rc == 0 and st["coarse_used"] == used
+        steps[coarse] = max(st["iterations"][:3])
+        for g, r in zip(outs, ref):
+            assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
+    print(which, precision, "PCG steps:", steps)
+    outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, coarse_degree=8, coarse_ratio=100))
+    assert rc == 0 and st["coarse_used"] == 1
+    outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner="local", rtol=1e-10, maxsteps=20000, coarse="amg"))
+    assert rc == 0 and st["coarse_used"] == 0
+
+
+@pytest.mark.gpu
+def test_multigrid_cycle_with_chunks_of_eight_and_one(mesh2d, gpu_ctx):
+    """Nine right-hand sides -> the cycle runs with 8 columns and with 1; every column equals its single-RHS solve."""
+    from remo3d_amd import solver
+    zs = np.linspace(-0.4, 0.4, 9)
+    src = [([z], [1.0]) for z in zs]
+    ev = [[z + 0.4, z + 6.4] for z in zs]
+    opts = solver.make_opts(rtol=1e-12, maxsteps=20000, coarse="amg")
+    outs, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, src, ev, opts)
+    assert rc == 0 and st["coarse_used"] == 2
+    for i in (0, 4, 7, 8):
+        single, _, rc1 = gpu_ctx.solve_batch(mesh2d, SIGMA3, [src[i]], [ev[i]], opts)
+        assert rc1 == 0
+        assert np.allclose(outs[i], single[0], rtol=1e-9, atol=0)
+
+
+@pytest.mark.gpu
+def test_multigrid_cycle_is_reproducible_and_cuts_the_steps_on_a_config2_batch(gpu_ctx, examples_dir):
+    """One batch of BASELINE configs[1] (Benchmark model 1, 80 k vertices): the hierarchy is built without floating-point
+    atomics, so two runs give bit-identical potentials; the cycle needs at most 0.75 x the PCG steps of the polynomial."""
+    import os
+    from remo3d_amd import geometry, solver, tasks
+    from remo3d_amd.model import Model, default_mesh_provider
+    ex = os.path.join(examples_dir, "Benchmark models", "Benchmark model 1")
+    m = Model(["A0.4M6.0N"])
+    m.set_model_parameters(os.path.join(ex, "Formation_BM1.txt"), os.path.join(ex, "Borehole_BM1.txt"))
+    sim, batches = tasks.build_batches(m.tools, m.sec, np.linspace(5, 55, 100), 5)
+    mud = np.interp(sim, m.borehole_model[:, 0], m.borehole_model[:, 2])
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    fg, bh, sigma = geometry.select_netgen_data_range(bg, m.formation_model, mud[5], sim[5], 50.0)
+    mesh = default_mesh_provider()(2, 50.0, batches[5], fg, bh, 0.0)
+    sources, evals, _ = tasks.batch_rhs(batches[5], m.tools)
+    got = {}
+    for coarse in ("chebyshev", "amg", "amg"):
+        outs, st, rc = gpu_ctx.solve_batch(mesh, sigma, sources, evals, solver.make_opts(rtol=1e-10, coarse=coarse))
+        assert rc == 0
+        got.setdefault(coarse, []).append((np.concatenate(outs), st["pcg_steps"]))
+    (uc, sc), = got["chebyshev"]
+    (u1, s1), (u2, s2) = got["amg"]
+    print("PCG steps: chebyshev", sc, "cycle", s1)
+    assert np.array_equal(u1, u2) and s1 == s2
+    assert np.max(np.abs(u1 - uc) / np.abs(uc)) < 1e-7
+    assert s1 <= 0.75 * sc

@@ -74,6 +74,47 @@ def _build_some(job):
     return out
 
 
+def _model_and_batches_2d():
+    import numpy as np
+    from remo3d_amd import tasks
+    from remo3d_amd.model import Model
+    ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 1")
+    m = Model(["A0.4M6.0N"])
+    m.set_model_parameters(os.path.join(ex, "Formation_BM1.txt"), os.path.join(ex, "Borehole_BM1.txt"))
+    depths = np.linspace(5, 55, 100)
+    sim, batches = tasks.build_batches(m.tools, m.sec, depths, 5)
+    mud = np.interp(sim, m.borehole_model[:, 0], m.borehole_model[:, 2])
+    bg = np.ascontiguousarray(m.borehole_model[:, :2])
+    return m, depths, sim, batches, mud, bg
+
+
+def _build_some_2d(indices):
+    from remo3d_amd import geometry, tasks
+    from remo3d_amd.model import default_mesh_provider
+    m, depths, sim, batches, mud, bg = _model_and_batches_2d()
+    provider = default_mesh_provider()
+    out = []
+    for bi in indices:
+        fg, bh, sigma = geometry.select_netgen_data_range(bg, m.formation_model, mud[bi], sim[bi], 50.0)
+        sources, evals, readers = tasks.batch_rhs(batches[bi], m.tools)
+        out.append(dict(index=bi, mesh=provider(2, 50.0, batches[bi], fg, bh, 0.0), sigma=sigma, sources=sources, evals=evals, readers=readers))
+    return out
+
+
+def build_workload_2d(nb, pool=None):
+    """BASELINE configs[1]: Benchmark model 1 (2D axisymmetric), tool A0.4M6.0N, 100 depths in batches of 5, default mesh
+    scale (the one that meets the reference's logs): nb of the 20 batches, evenly spread over the log."""
+    m, depths, sim, batches, mud, bg = _model_and_batches_2d()
+    mine = list(range(0, len(batches), max(1, len(batches) // nb)))[:nb]
+    if pool is not None and len(mine) > 1:
+        nw = getattr(pool, "_max_workers", 4)
+        futs = [pool.submit(_build_some_2d, mine[i::nw]) for i in range(nw) if mine[i::nw]]
+        work = sorted((w for f in futs for w in f.result()), key=lambda w: w["index"])
+    else:
+        work = _build_some_2d(mine)
+    return dict(model=m, depths=depths[:5 * len(mine)], n_batches=len(batches), work=work, names=["A0.4M6.0N"])
+
+
 def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice", total_depths=None, all_batches=False, max_batches=None,
                    pool=None):
     """Batches of this rank (block-cyclic share; all of them when all_batches) with meshes and right-hand sides.
@@ -220,7 +261,7 @@ class Runner:
         agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
         for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
             agg[k] += st[k]
-        agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]; agg["batches"] += 1; agg["op_used"] = st["op_used"]
+        agg["n"] = st["n_free"]; agg["nnz"] = st["nnz"]; agg["batches"] += 1; agg["op_used"] = st["op_used"]; agg["coarse_used"] = st["coarse_used"]
 
     def one_step(self, h2d_inclusive=False):
         np = self.np
@@ -320,9 +361,10 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8",
+    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
-                         "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size), reported in the `sizes` array; '' = none")
+                         "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size; '2D-BM1' = BASELINE configs[1], "
+                         "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
@@ -354,7 +396,9 @@ def main():
             name, nb = spec.split(":")
             conf = name.startswith("conforming-")
             size = name.split("/")[0].split("-")[-1]
-            if not (name == args.size):
+            if name.startswith("2D"):
+                extra_specs.append((name, "2D", "2D", int(nb)))
+            elif not (name == args.size):
                 extra_specs.append((name, size, "conforming" if conf else "lattice", int(nb)))
 
     # ---- synthetic meshes: CPU-only worker processes, before this process loads the HIP library ----
@@ -373,7 +417,8 @@ def main():
     extra_wl = []
     for name, size, kind, nb in extra_specs:     # the 20-depth sweep of the same model: 8 batches; variants of one size share its meshes
         if (size, kind, nb) not in built:
-            built[(size, kind, nb)] = build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool)
+            built[(size, kind, nb)] = (build_workload_2d(nb, pool=mesh_pool) if kind == "2D" else
+                                       build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool))
         extra_wl.append((name, built[(size, kind, nb)]))
     if mesh_pool is not None:
         mesh_pool.shutdown()
@@ -480,15 +525,16 @@ def main():
     for name, w2 in extra_wl:
         prec2 = "mixed" if "/mixed" in name else args.precision
         op2 = "element" if "/element" in name else ("csr" if "/csr" in name else args.op)
+        coarse2 = "chebyshev" if "/chebyshev" in name else "auto"
         opts2 = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
-                                 time_kernels=0 if args.no_events else stride, precision=prec2, op=op2)
+                                 time_kernels=0 if args.no_events else stride, precision=prec2, op=op2, coarse=coarse2)
         r2 = Runner(w2["work"], len(w2["depths"]), local, opts2)
         st2 = 2
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
         pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
         rf = roofline_of(agg2, prec2, stride)
         op2 = "element" if agg2["op_used"] else "csr"
-        sizes.append(dict(workload=name, precision=prec2, operator=op2, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
+        sizes.append(dict(workload=name, precision=prec2, operator=op2, vertex_block_solver={0: "none", 1: "chebyshev", 2: "multigrid cycle"}[agg2.get("coarse_used", 1)], batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
                           n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
                           max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"] if op2 == "csr" else None, apply_avg_launch_us=rf["avg_launch_us"],
                           solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))

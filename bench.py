@@ -112,7 +112,7 @@ def build_workload_2d(nb, pool=None):
         work = sorted((w for f in futs for w in f.result()), key=lambda w: w["index"])
     else:
         work = _build_some_2d(mine)
-    return dict(model=m, depths=depths[:5 * len(mine)], n_batches=len(batches), work=work, names=["A0.4M6.0N"])
+    return dict(model=m, depths=depths, n_batches=len(batches), work=work, names=["A0.4M6.0N"])   # the slab of results is indexed by the depth's place in the whole log
 
 
 def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice", total_depths=None, all_batches=False, max_batches=None,
@@ -254,7 +254,7 @@ class Runner:
         outs = b.fetch()
         for u, rd in zip(outs, w["readers"]):
             for (di, ti, K, o, m) in rd:
-                slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, 3)
+                slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, w["mesh"].dim)
         agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
         agg["spmv_ms_raw"] += st["spmv_ms_raw"]; agg["ev_over"] = st["event_overhead_ms"]
         agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
@@ -274,7 +274,7 @@ class Runner:
                 outs, st, rc = self.ctxs[0].solve_batch(w["mesh"], w["sigma"], w["sources"], w["evals"], self.opts, raise_on_error=False)
                 for u, rd in zip(outs, w["readers"]):
                     for (di, ti, K, o, m) in rd:
-                        slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, 3) if rc >= 0 else np.nan
+                        slab[di, ti] = self.tasks.apparent_resistivity(u[o:o + m], m, K, w["mesh"].dim) if rc >= 0 else np.nan
                 agg["ms_h2d"] += st["ms_h2d"]; agg["batches"] += 1
         elif self.pool is not None:   # one host thread per context, each walks its own batches in order (ctypes releases the GIL)
             def drive(j):

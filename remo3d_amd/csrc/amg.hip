@@ -8,7 +8,8 @@
 //   aggregation   distance-2 maximal independent set of the matrix graph by hashed priorities (Bell / Dalton / Olson 2012):
 //                 roots, then their neighbours, then the neighbours' neighbours by the strongest connection
 //   prolongator   P = (I - 4 / (3 lmax) D^-1 A) P0, one generic row-wise sparse product (LDS hash set per wave for the
-//                 pattern, sorted; values by sorted-row lookups in a fixed order), R = P^T by a radix sort of (column, row)
+//                 pattern, sorted; values by sorted-row lookups in a fixed order),
+//                 R = P^T by count / scan / scatter and an LDS sort of every row
 //   coarse matrix A' = R (A P), two more products
 //   coarsest      dense inverse (Gauss-Jordan in LDS, <= 64 rows)
 // Cycle: V(1,1) with damped Jacobi (omega = 1.6 / lmax, the one-term Chebyshev polynomial of [lmax / 4, lmax]), symmetric, so
@@ -16,10 +17,12 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -271,27 +274,51 @@ __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__res
     }
 }
 
-// ---- transpose by sorting (column << 32 | row) ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_transpose_keys(int64_t n, int rbits, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        uint64_t *__restrict__ keys) {
+// ---- transpose without a device-wide sort: count, scan, scatter in any order, then every row sorted by a wave in LDS --------
+__global__ void __launch_bounds__(256) k_tr_count(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int32_t *__restrict__ cnt) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) keys[p] = (uint64_t(uint32_t(col[p])) << rbits) | uint64_t(uint32_t(i));
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) atomicAdd(&cnt[col[p]], 1);
 }
-
-__global__ void __launch_bounds__(256) k_transpose_finish(int64_t ncols, int64_t nnz, int rbits, const uint64_t *__restrict__ keys, int32_t *__restrict__ rp,
-                                                          int32_t *__restrict__ rc) {
-    const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t < nnz) rc[t] = int32_t(uint32_t(keys[t] & ((uint64_t(1) << rbits) - 1)));
-    if (t <= ncols) {
-        const uint64_t key = uint64_t(t) << rbits;
-        int64_t lo = 0, hi = nnz;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        rp[t] = int32_t(lo);
+__global__ void __launch_bounds__(256) k_tr_fill(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                 const int32_t *__restrict__ rrp, int32_t *__restrict__ cursor, int32_t *__restrict__ rc, double *__restrict__ rv) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+        const int32_t c = col[p];
+        const int32_t at = rrp[c] + atomicAdd(&cursor[c], 1);
+        rc[at] = int32_t(i);
+        rv[at] = val[p];
     }
+}
+constexpr int kTrMax = 512;   // longest row of R the LDS sort takes
+__global__ void __launch_bounds__(256) k_tr_sort(int64_t nr, const int32_t *__restrict__ rrp, int32_t *__restrict__ rc, double *__restrict__ rv, int32_t *flag) {
+    __shared__ int32_t keys[4][kTrMax];
+    __shared__ double vals[4][kTrMax];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    if (row >= nr) return;
+    const int32_t rs = rrp[row], len = rrp[row + 1] - rs;
+    if (len <= 1) return;
+    if (len > kTrMax) { if (lane == 0) atomicOr(flag, 4); return; }
+    int32_t *K = keys[wave];
+    double *V = vals[wave];
+    int m = 64;
+    while (m < len) m <<= 1;
+    for (int t = lane; t < m; t += 64) { K[t] = t < len ? rc[rs + t] : INT_MAX; V[t] = t < len ? rv[rs + t] : 0.0; }
+    wave_sync();
+    for (int size = 2; size <= m; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < m / 2; t += 64) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int32_t a = K[lo], b = K[hi];
+                if ((a > b) == up) { K[lo] = b; K[hi] = a; const double x = V[lo]; V[lo] = V[hi]; V[hi] = x; }
+            }
+            wave_sync();
+        }
+    for (int t = lane; t < len; t += 64) { rc[rs + t] = K[t]; rv[rs + t] = V[t]; }
 }
 
 // ---- dense inverse of the coarsest operator: in-place Gauss-Jordan in LDS, no pivoting (symmetric positive definite) --------
@@ -543,45 +570,48 @@ struct Csr {
     double *val = nullptr;
 };
 
-int64_t spgemm(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const Csr &Y, int32_t *d_flag, Csr &C) {
+// variant 1: a wave per row with 128 hash slots, 2: with 512.  `hint` remembers the variant that worked for this product of this
+// level the last time (process-wide; meshes of a sweep look alike).  (Variant 0 was one LANE per row with a private sorted
+// list of at most 32 columns for the short rows of S P0 and A P: 230 us per launch against 70 - private arrays with dynamic
+// indices live in scratch memory; removed.)
+template <int PASS>
+void launch_product(int variant, hipStream_t s, const Csr &X, const Csr &Y, int32_t *cnt, const int32_t *crp, int32_t *cc, double *cv, int32_t *d_over) {
+    if (variant <= 1)
+        hipLaunchKernelGGL((k_spgemm<PASS, 128>), dim3(grid_rows(X.n, 4)), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, crp, cc, cv, d_over);
+    else
+        hipLaunchKernelGGL((k_spgemm<PASS, 512>), dim3(grid_rows(X.n, 4)), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, crp, cc, cv, d_over);
+}
+
+int64_t spgemm(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const Csr &Y, int32_t *d_flag, Csr &C, std::atomic<int> &hint, int first_variant) {
     C.n = X.n;
     C.rowptr = permanent ? ar.lo<int32_t>(size_t(X.n) + 2) : ar.hi<int32_t>(size_t(X.n) + 2);
-    const int g = grid_rows(X.n, 4);
-    int32_t *d_over = d_flag + 40;   // overflow of the product's hash tables, apart from the setup's other flags
-    for (int slots = 128; slots <= 512; slots *= 4) {
+    int32_t *d_over = d_flag + 40;   // overflow of the product's tables, apart from the setup's other flags
+    int start = hint.load(std::memory_order_relaxed);
+    if (start < first_variant) start = first_variant;
+    for (int variant = start; variant <= 2; ++variant) {
         const size_t mark = ar.hi_mark();
         int32_t *cnt = ar.hi<int32_t>(size_t(X.n) + 2);
         HIP_OK(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
-        if (slots == 128)
-            hipLaunchKernelGGL((k_spgemm<0, 128>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, (const int32_t *)nullptr,
-                               (int32_t *)nullptr, (double *)nullptr, d_over);
-        else
-            hipLaunchKernelGGL((k_spgemm<0, 512>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, (const int32_t *)nullptr,
-                               (int32_t *)nullptr, (double *)nullptr, d_over);
+        launch_product<0>(variant, s, X, Y, cnt, nullptr, nullptr, nullptr, d_over);
         scan_counts(ar, s, X.n, cnt, C.rowptr);
         int32_t h[2] = {0, 0};
         HIP_OK(hipMemcpyAsync(&h[0], C.rowptr + X.n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_OK(hipMemcpyAsync(&h[1], d_over, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         ar.hi_release(mark);
-        if (h[1] != 0) {
-            if (slots == 512) return -1;
-            continue;
-        }
+        if (h[1] != 0) continue;
         if (h[0] <= 0 || h[0] == INT_MAX) return -1;
+        hint.store(variant, std::memory_order_relaxed);
         C.nnz = h[0];
         C.col = permanent ? ar.lo<int32_t>(size_t(C.nnz) + 2) : ar.hi<int32_t>(size_t(C.nnz) + 2);
         C.val = permanent ? ar.lo<double>(size_t(C.nnz) + 2) : ar.hi<double>(size_t(C.nnz) + 2);
-        if (slots == 128)
-            hipLaunchKernelGGL((k_spgemm<1, 128>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, (int32_t *)nullptr,
-                               (const int32_t *)C.rowptr, C.col, C.val, d_over);
-        else
-            hipLaunchKernelGGL((k_spgemm<1, 512>), dim3(g), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, (int32_t *)nullptr,
-                               (const int32_t *)C.rowptr, C.col, C.val, d_over);
+        launch_product<1>(variant, s, X, Y, nullptr, C.rowptr, C.col, C.val, d_over);
         return C.nnz;
     }
     return -1;
 }
+
+std::atomic<int> g_product_hint[kAmgMaxLevels][3];   // zero-initialised: start with the cheapest variant
 
 }  // namespace
 
@@ -662,7 +692,8 @@ bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, cons
             }
             double lmax;
             std::memcpy(&lmax, &h_bound, sizeof lmax);
-            if (h_flag != 0 || !(lmax > 0.0) || !std::isfinite(lmax)) { why = "level operator without a positive diagonal"; ar.hi_release(hi0); return false; }
+            if (getenv("REMO_AMG_DEBUG")) fprintf(stderr, "amg level %d: n %lld nnz %lld, %d rounds of 6 independent-set iterations, lmax %.3f\n", L, (long long)n, (long long)A.nnz, rounds, lmax);
+            if (h_flag != 0 || !(lmax > 0.0) || !std::isfinite(lmax)) { why = "level setup raised flag " + std::to_string(h_flag) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort) or lost its spectrum bound"; ar.hi_release(hi0); return false; }
             lv.omega = 1.6 / lmax;
             hipLaunchKernelGGL(k_mis_flags, dim3(g), dim3(256), 0, s, n, tup, isroot);
             scan_counts(ar, s, n, isroot, id);
@@ -681,30 +712,26 @@ bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, cons
             const int64_t nc = h_nc;
             if (nc <= 0 || nc * 10 > n * 8) { why = "no coarsening"; ar.hi_release(hi0); return false; }
             Csr P;
-            if (spgemm(ar, true, s, S, P0, d_flag, P) < 0) { why = "prolongator row too long"; ar.hi_release(hi0); return false; }
+            if (spgemm(ar, true, s, S, P0, d_flag, P, g_product_hint[L][0], 1) < 0) { why = "prolongator row too long"; ar.hi_release(hi0); return false; }
             lv.p_rowptr = P.rowptr; lv.p_col = P.col; lv.p_val = P.val; lv.nnz_p = P.nnz;
             // ---- R = P^T ----
             Csr R;
             R.n = nc; R.nnz = P.nnz;
             R.rowptr = ar.lo<int32_t>(size_t(nc) + 2); R.col = ar.lo<int32_t>(size_t(P.nnz) + 2); R.val = ar.lo<double>(size_t(P.nnz) + 2);
-            {
-                uint64_t *k_in = ar.hi<uint64_t>(size_t(P.nnz) + 2), *k_out = ar.hi<uint64_t>(size_t(P.nnz) + 2);
-                int rbits = 1, cbits = 1;   // key = column << rbits | row: only the bits in use take part in the sort
-                while ((int64_t(1) << rbits) < n) ++rbits;
-                while ((int64_t(1) << cbits) < nc + 1) ++cbits;
-                hipLaunchKernelGGL(k_transpose_keys, dim3(g), dim3(256), 0, s, n, rbits, P.rowptr, P.col, k_in);
-                size_t tb = 0;
-                HIP_OK(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, P.val, R.val, size_t(P.nnz), 0u, unsigned(rbits + cbits), s));
-                void *tmp = ar.hi<char>(tb + 256);
-                HIP_OK(rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, P.val, R.val, size_t(P.nnz), 0u, unsigned(rbits + cbits), s));
-                const int64_t span = P.nnz > nc + 1 ? P.nnz : nc + 1;
-                hipLaunchKernelGGL(k_transpose_finish, dim3(grid_rows(span, 256)), dim3(256), 0, s, nc, P.nnz, rbits, k_out, R.rowptr, R.col);
+            {   // count the entries of every column, scan, scatter (any order), sort every row of R by its column = row of P
+                int32_t *tcnt = ar.hi<int32_t>(size_t(nc) + 2), *cursor = ar.hi<int32_t>(size_t(nc) + 2);
+                HIP_OK(hipMemsetAsync(tcnt, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
+                HIP_OK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
+                hipLaunchKernelGGL(k_tr_count, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, tcnt);
+                scan_counts(ar, s, nc, tcnt, R.rowptr);
+                hipLaunchKernelGGL(k_tr_fill, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, P.val, R.rowptr, cursor, R.col, R.val);
+                hipLaunchKernelGGL(k_tr_sort, dim3(grid_rows(nc, 4)), dim3(256), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
             }
             lv.r_rowptr = R.rowptr; lv.r_col = R.col; lv.r_val = R.val;
             // ---- A' = R (A P) ----
             Csr AP, Ac;
-            if (spgemm(ar, false, s, A, P, d_flag, AP) < 0) { why = "A P row too long"; ar.hi_release(hi0); return false; }
-            if (spgemm(ar, true, s, R, AP, d_flag, Ac) < 0) { why = "coarse row too long"; ar.hi_release(hi0); return false; }
+            if (spgemm(ar, false, s, A, P, d_flag, AP, g_product_hint[L][1], 1) < 0) { why = "A P row too long"; ar.hi_release(hi0); return false; }
+            if (spgemm(ar, true, s, R, AP, d_flag, Ac, g_product_hint[L][2], 1) < 0) { why = "coarse row too long"; ar.hi_release(hi0); return false; }
             HIP_OK(hipStreamSynchronize(s));   // the scratch of this level is released next
             ar.hi_release(mark);
             A = Ac;
@@ -715,7 +742,7 @@ bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, cons
         HIP_OK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         ar.hi_release(hi0);
-        if (h_flag != 0) { why = "coarsest operator not positive definite"; return false; }
+        if (h_flag != 0) { why = "setup raised flag " + std::to_string(h_flag) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort)"; return false; }
         H.launches = 4 * (H.levels - 1) + 1;
         return true;
     } catch (const std::exception &ex) {

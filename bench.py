@@ -361,10 +361,10 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8",
+    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8,2D-BM1/2ctx:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
                          "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size; '2D-BM1' = BASELINE configs[1], "
-                         "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block), reported in the `sizes` array; '' = none")
+                         "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block, '/2ctx' = two contexts (streams, host threads) share the batches), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
@@ -528,13 +528,13 @@ def main():
         coarse2 = "chebyshev" if "/chebyshev" in name else "auto"
         opts2 = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                                  time_kernels=0 if args.no_events else stride, precision=prec2, op=op2, coarse=coarse2)
-        r2 = Runner(w2["work"], len(w2["depths"]), local, opts2)
+        r2 = Runner(w2["work"], len(w2["depths"]), local, opts2, streams=2 if "/2ctx" in name else 1)
         st2 = 2
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
         pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
         rf = roofline_of(agg2, prec2, stride)
         op2 = "element" if agg2["op_used"] else "csr"
-        sizes.append(dict(workload=name, precision=prec2, operator=op2, vertex_block_solver={0: "none", 1: "chebyshev", 2: "multigrid cycle"}[agg2.get("coarse_used", 1)], batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
+        sizes.append(dict(workload=name, precision=prec2, operator=op2, vertex_block_solver={0: "none", 1: "chebyshev", 2: "multigrid cycle"}[agg2.get("coarse_used", 1)], contexts=2 if "/2ctx" in name else 1, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
                           n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
                           max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"] if op2 == "csr" else None, apply_avg_launch_us=rf["avg_launch_us"],
                           solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))

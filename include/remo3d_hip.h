@@ -205,7 +205,7 @@ int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes
  * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
  * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
  * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides).  Process-global. */
+ * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage).  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -46,7 +46,9 @@ void amg_to_float(Arena &ar, hipStream_t s, const AmgT<double> &in, int kmax, Am
 
 // z = V(1,1)-cycle(r) on the vertex rows; the last launch stores cz = z / dinv (the direction kernel treats it like r) and the
 // <r, z> partial sums of `nblocks` workgroups [nblocks][k] in part.  scal / step: early exit of finished solves (kernels.hip)
-template <class T> void launch_amg_cycle(const AmgT<T> &H, int k, int step, const T *r, T *cz, double *part, int nblocks, const double *scal,
-                                         hipStream_t s);
+// T = storage type of the hierarchy, TR = type of r and cz: <float, double> is the cycle in fp32 inside an fp64 solve (a
+// preconditioner may be applied inexactly; the recurrences of x and r never see it)
+template <class T, class TR> void launch_amg_cycle(const AmgT<T> &H, int k, int step, const TR *r, TR *cz, double *part, int nblocks, const double *scal,
+                                                   hipStream_t s);
 
 }  // namespace remo

@@ -362,9 +362,9 @@ template <class S, class D> __global__ void __launch_bounds__(256) k_convert(int
 // per-operation kernels of the large levels and the single-workgroup kernel that walks all small levels (k_amg_tail).
 constexpr int kLpr = 8;
 
-template <class T, int K, bool SCALE, int LPR = kLpr>
+template <class T, int K, bool SCALE, int LPR = kLpr, class TX = T>
 __device__ __forceinline__ void row_product(int32_t rs, int32_t re, int sub, const int32_t *__restrict__ col, const T *__restrict__ val,
-                                            const T *__restrict__ dinv, const T *__restrict__ x, T (&acc)[K]) {
+                                            const T *__restrict__ dinv, const TX *__restrict__ x, T (&acc)[K]) {
 #pragma unroll
     for (int c = 0; c < K; ++c) acc[c] = T(0);
     for (int32_t p0 = rs + sub; p0 < re; p0 += 2 * LPR) {   // two passes of loads in flight
@@ -382,9 +382,9 @@ __device__ __forceinline__ void row_product(int32_t rs, int32_t re, int sub, con
             for (int c = 0; c < K; ++c) xv[u][c] = T(0);
             if (j[u] >= 0) {
                 if (SCALE) a[u] *= dinv[j[u]];
-                const T *xr = x + int64_t(j[u]) * K;
+                const TX *xr = x + int64_t(j[u]) * K;
 #pragma unroll
-                for (int c = 0; c < K; ++c) xv[u][c] = xr[c];
+                for (int c = 0; c < K; ++c) xv[u][c] = T(xr[c]);
             }
         }
 #pragma unroll
@@ -410,12 +410,12 @@ template <int K, int LPR = kLpr> __device__ __forceinline__ Lane lane_of(int tid
 }
 
 // first half on a level: z = w D^-1 r (from zero), t = r - A z
-template <class T, int K> __device__ __forceinline__ void op_pre(const AmgLevelT<T> &a, const T *__restrict__ r, int64_t row, const Lane &ln) {
+template <class T, int K, class TR = T> __device__ __forceinline__ void op_pre(const AmgLevelT<T> &a, const TR *__restrict__ r, int64_t row, const Lane &ln) {
     T acc[K];
-    row_product<T, K, true>(a.rowptr[row], a.rowptr[row + 1], ln.sub, a.col, a.val, a.dinv, r, acc);
+    row_product<T, K, true, kLpr, TR>(a.rowptr[row], a.rowptr[row + 1], ln.sub, a.col, a.val, a.dinv, r, acc);
     if (ln.mine) {
         const int64_t at = row * K + ln.mycol;
-        const T w = T(a.omega), ri = r[at];
+        const T w = T(a.omega), ri = T(r[at]);
         a.z[at] = w * a.dinv[row] * ri;
         a.t[at] = ri - w * acc[0];
     }
@@ -433,29 +433,30 @@ template <class T, int K> __device__ __forceinline__ void op_prolong(const AmgLe
     if (ln.mine) a.z[row * K + ln.mycol] += acc[0];
 }
 // second half: zout = z + w D^-1 (r - A z); LAST (finest level): zout / dinv is stored, the return value is r * zout
-template <class T, int K, bool LAST>
-__device__ __forceinline__ double op_post(const AmgLevelT<T> &a, const T *__restrict__ r, T *__restrict__ zout, int64_t row, const Lane &ln) {
+template <class T, int K, bool LAST, class TR = T>
+__device__ __forceinline__ double op_post(const AmgLevelT<T> &a, const TR *__restrict__ r, TR *__restrict__ zout, int64_t row, const Lane &ln) {
     T acc[K];
     row_product<T, K, false>(a.rowptr[row], a.rowptr[row + 1], ln.sub, a.col, a.val, (const T *)nullptr, (const T *)a.z, acc);
     double dot = 0.0;
     if (ln.mine) {
         const int64_t at = row * K + ln.mycol;
-        const T ri = r[at], di = a.dinv[row];
+        const TR rr = r[at];
+        const T ri = T(rr), di = a.dinv[row];
         const T zn = a.z[at] + T(a.omega) * di * (ri - acc[0]);
-        zout[at] = LAST ? zn / di : zn;
-        dot = double(ri) * double(zn);
+        zout[at] = TR(LAST ? zn / di : zn);
+        dot = double(rr) * double(zn);
     }
     return dot;
 }
 
 constexpr int kRpb = 256 / kLpr;   // rows per workgroup of the one-operation kernels
 
-template <class T, int K>
-__global__ void __launch_bounds__(256) k_amg_pre(AmgLevelT<T> a, const T *__restrict__ r, const double *scal, int step) {
+template <class T, int K, class TR>
+__global__ void __launch_bounds__(256) k_amg_pre(AmgLevelT<T> a, const TR *__restrict__ r, const double *scal, int step) {
     if (amg_done(scal, step)) return;
     const Lane ln = lane_of<K>(threadIdx.x);
     const int64_t row = int64_t(blockIdx.x) * kRpb + threadIdx.x / kLpr;
-    if (row < a.n) op_pre<T, K>(a, r, row, ln);
+    if (row < a.n) op_pre<T, K, TR>(a, r, row, ln);
 }
 template <class T, int K>
 __global__ void __launch_bounds__(256) k_amg_restrict(AmgLevelT<T> a, int64_t n_next, T *__restrict__ rn, const double *scal, int step) {
@@ -473,15 +474,15 @@ __global__ void __launch_bounds__(256) k_amg_prolong(AmgLevelT<T> a, const T *__
 }
 // (prolongation folded into this sweep - P z_next formed on the fly for the row and its neighbours - was measured: 24.7 us
 // against 5.3 + 12 at 80 k rows, the inner loops over P's rows are chains of dependent loads)
-template <class T, int K, bool LAST, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_amg_post(AmgLevelT<T> a, const T *__restrict__ r, T *__restrict__ zout,
+template <class T, int K, bool LAST, int THREADS, class TR>
+__global__ void __launch_bounds__(THREADS) k_amg_post(AmgLevelT<T> a, const TR *__restrict__ r, TR *__restrict__ zout,
                                                      double *__restrict__ part, const double *scal, int step) {
     if (amg_done(scal, step)) return;
     const Lane ln = lane_of<K>(threadIdx.x);
     constexpr int RPB = THREADS / kLpr;
     double dot = 0.0;
     for (int64_t row = int64_t(blockIdx.x) * RPB + threadIdx.x / kLpr; row < a.n; row += int64_t(gridDim.x) * RPB)
-        dot += op_post<T, K, LAST>(a, r, zout, row, ln);
+        dot += op_post<T, K, LAST, TR>(a, r, zout, row, ln);
     if (LAST) {   // <r, z> partials of the workgroup, one per column
         constexpr int NW = THREADS / 64;
         __shared__ double smem[NW * K];
@@ -780,7 +781,7 @@ void amg_to_float(Arena &ar, hipStream_t s, const AmgT<double> &in, int kmax, Am
     out.inv = conv(in.inv, size_t(nc * nc));
 }
 
-template <class T> void launch_amg_cycle(const AmgT<T> &H, int k, int step, const T *r, T *cz, double *part, int nblocks, const double *scal, hipStream_t s) {
+template <class T, class TR> void launch_amg_cycle(const AmgT<T> &H, int k, int step, const TR *r, TR *cz, double *part, int nblocks, const double *scal, hipStream_t s) {
     const int L = H.levels;
 #define AMG_K_SWITCH(CALL)                                  \
     switch (k) {                                            \
@@ -799,8 +800,11 @@ template <class T> void launch_amg_cycle(const AmgT<T> &H, int k, int step, cons
     while (lt > 1 && H.lev[lt - 1].n <= kTailRows && L - (lt - 1) <= kTailLevels) --lt;
     for (int l = 0; l < lt; ++l) {   // down
         const AmgLevelT<T> &a = H.lev[l], &b = H.lev[l + 1];
-        const T *rl = (l == 0) ? r : (const T *)a.r;
-        AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_pre<T, KK>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, rl, scal, step));
+        if (l == 0) {
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_pre<T, KK, TR>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, r, scal, step));
+        } else {
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_pre<T, KK, T>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, (const T *)a.r, scal, step));
+        }
         if (l + 1 < lt) AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_restrict<T, KK>), dim3(rows_grid(b.n)), dim3(256), 0, s, a, b.n, b.r, scal, step));
     }
     {
@@ -813,18 +817,18 @@ template <class T> void launch_amg_cycle(const AmgT<T> &H, int k, int step, cons
     }
     for (int l = lt - 1; l >= 0; --l) {   // up
         const AmgLevelT<T> &a = H.lev[l], &b = H.lev[l + 1];
-        const T *rl = (l == 0) ? r : (const T *)a.r;
         AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_prolong<T, KK>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, (const T *)b.z2, scal, step));
         if (l == 0) {   // the launch that leaves the partial sums is held to `nblocks` workgroups: 128 rows each
-            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, true, 1024>), dim3(nblocks), dim3(1024), 0, s, a, rl, cz, part, scal, step));
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, true, 1024, TR>), dim3(nblocks), dim3(1024), 0, s, a, r, cz, part, scal, step));
         } else {
-            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, false, 256>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, rl, a.z2, (double *)nullptr, scal, step));
+            AMG_K_SWITCH(hipLaunchKernelGGL((k_amg_post<T, KK, false, 256, T>), dim3(rows_grid(a.n)), dim3(256), 0, s, a, (const T *)a.r, a.z2, (double *)nullptr, scal, step));
         }
     }
 #undef AMG_K_SWITCH
 }
 
-template void launch_amg_cycle<double>(const AmgT<double> &, int, int, const double *, double *, double *, int, const double *, hipStream_t);
-template void launch_amg_cycle<float>(const AmgT<float> &, int, int, const float *, float *, double *, int, const double *, hipStream_t);
+template void launch_amg_cycle<double, double>(const AmgT<double> &, int, int, const double *, double *, double *, int, const double *, hipStream_t);
+template void launch_amg_cycle<float, float>(const AmgT<float> &, int, int, const float *, float *, double *, int, const double *, hipStream_t);
+template void launch_amg_cycle<float, double>(const AmgT<float> &, int, int, const double *, double *, double *, int, const double *, hipStream_t);
 
 }  // namespace remo

@@ -48,6 +48,7 @@ template <class T> struct PcgBuffersT {
     float *c32_z = nullptr, *c32_res = nullptr, *c32_d[2] = {nullptr, nullptr};
     // multigrid cycle on the vertex block instead of the polynomial (amg.h; 2D by default); nullptr -> Chebyshev
     const AmgT<T> *amg = nullptr;
+    const AmgT<float> *amg32 = nullptr;   // fp64 solves: the cycle in fp32 storage (remo_debug_tune key 17), nullptr -> in T
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)

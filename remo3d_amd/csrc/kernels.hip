@@ -1505,7 +1505,13 @@ template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b) {
 template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step, const PcgBuffersT<T> &b, double *part_slot, hipStream_t s, bool first_done = false) {
     if (b.cheb_degree <= 0 || b.nv_coarse <= 0) return;
     if (b.amg) {   // multigrid cycle instead of the polynomial (amg.hip)
-        launch_amg_cycle(*b.amg, k, step, (const T *)b.r, b.cz, part_slot + int64_t(b.nb_vec) * k, cheb_grid(b.nv_coarse), (const double *)b.rz0, s);
+        if constexpr (sizeof(T) == 8) {
+            if (b.amg32) {
+                launch_amg_cycle<float, double>(*b.amg32, k, step, (const double *)b.r, b.cz, part_slot + int64_t(b.nb_vec) * k, cheb_grid(b.nv_coarse), (const double *)b.rz0, s);
+                return;
+            }
+        }
+        launch_amg_cycle<T, T>(*b.amg, k, step, (const T *)b.r, b.cz, part_slot + int64_t(b.nb_vec) * k, cheb_grid(b.nv_coarse), (const double *)b.rz0, s);
         return;
     }
     if (b.sq_rowptr && (b.cheb_degree & 1) == 0) {   // two Richardson factors of the Chebyshev polynomial per launch

@@ -138,6 +138,7 @@ struct ChunkResult {
 std::mutex g_solve_mutex;   // remo_opts_t.serialize_solves
 int g_square = 1;   // remo_debug_tune key 6: 0 = one launch per Chebyshev step, 1 = paired steps in 2D, 2 = paired steps always
 int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row length)
+int g_amg32 = 1;     // key 17: 1 = fp64 solves run the multigrid cycle in fp32 storage (default), 0 = in fp64
 int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
@@ -516,7 +517,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
         need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
         const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2 && o.coarse_degree <= 0));   // an explicit degree asks for the polynomial
-        if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * (o.precision == 1 ? 2 : 1) + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
+        if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * 2 + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;
         if (o.precision == 1)
@@ -664,6 +665,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             if (amg_setup(ctx->ar, s, buf.nv_coarse, sy.rowptr, sy.col, d_val, kmax, b->amg64, why)) buf.amg = &b->amg64;
             else if (o.coarse == 2 || g_amg == 2) return fail(ctx, REMO_ERR_NUMERIC, "multigrid hierarchy of the vertex block: " + why);
         }
+        bool amg32_ready = false;
+        if (buf.amg && (o.precision == 1 || g_amg32)) {   // fp32 image of the hierarchy: the mixed mode's inner solver, or the cycle of an fp64 solve
+            amg_to_float(ctx->ar, s, b->amg64, kmax, b->amg32);
+            amg32_ready = true;
+            if (o.precision == 0) buf.amg32 = &b->amg32;
+        }
         st->coarse_used = !two_level ? 0 : (buf.amg ? 2 : 1);
         if (two_level) {
             double lmax;
@@ -732,10 +739,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             f.cd[0] = ctx->take<float>(nc); f.cd[1] = ctx->take<float>(nc);
             f.progress = buf.progress; f.progress_len = buf.progress_len;
             f.nb_spmv = buf.nb_spmv; f.nb_vec = buf.nb_vec;
-            if (buf.amg) {
-                amg_to_float(ctx->ar, s, b->amg64, kmax, b->amg32);
-                f.amg = &b->amg32;
-            }
+            if (buf.amg && amg32_ready) f.amg = &b->amg32;
             if (buf.vb_rowptr) {
                 float *vb32 = ctx->take<float>(size_t(h_vb[1]) + 1);
                 launch_to_float(h_vb[1], buf.vb_val, vb32, s);
@@ -971,6 +975,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;
     else if (key == 16) g_amg = value;
+    else if (key == 17) g_amg32 = value;
     else set_spmm_tuning(key, value);
 }
 

@@ -179,6 +179,12 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *batch, int32_t *rowptr,
  * With remo_batch_spmv this lets a test measure the TRUE residual f - A x of what CGSolver's silent stopping rule
  * (ngsolve_functions.py:50-51) left behind. */
 int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *batch, double *x, double *f, int32_t *k_out);
+/* Inspection hook (tests): z = one application of the multigrid cycle the last run built on the P1 block (remo_opts_t.coarse;
+ * replaces the "multigrid" preconditioner object of ngsolve_functions.py:46 on that block) to k column-interleaved vectors
+ * r[nv][k]; fp32 != 0: through the fp32 image of the hierarchy (what fp64 solves use by default).  nv_out receives the block size
+ * (r and z may be NULL to ask for it).  Fails when the last run used the polynomial. */
+int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out);
+
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */
 int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *x, double *y,

@@ -33,6 +33,7 @@ template <class T> struct AmgT {
     AmgLevelT<T> lev[kAmgMaxLevels];
     const T *inv = nullptr;        // dense inverse of the coarsest operator [nc][nc]
     int launches = 0;              // kernel launches of one cycle
+    int kmax = 0;                  // columns the level vectors were allocated for
 };
 
 // Build the hierarchy (fp64) of the leading nv x nv block of A (rows' vertex entries lead: columns ascend).  Everything is

@@ -758,6 +758,7 @@ bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, cons
         ar.hi_release(hi0);
         if (h_flag != 0) { why = "setup raised flag " + std::to_string(h_flag) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort)"; return false; }
         H.launches = 4 * (H.levels - 1) + 1;
+        H.kmax = kmax;
         return true;
     } catch (const std::exception &ex) {
         ar.hi_release(hi0);
@@ -775,6 +776,7 @@ void amg_to_float(Arena &ar, hipStream_t s, const AmgT<double> &in, int kmax, Am
     out = AmgT<float>{};
     out.levels = in.levels;
     out.launches = in.launches;
+    out.kmax = kmax;
     for (int l = 0; l < in.levels; ++l) {
         const AmgLevelT<double> &a = in.lev[l];
         AmgLevelT<float> &b = out.lev[l];

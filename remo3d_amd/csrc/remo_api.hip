@@ -478,6 +478,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
     std::memset(st, 0, sizeof *st);
     std::fill(b->u_out.begin(), b->u_out.end(), std::nan(""));
     b->has_system = false;
+    b->amg64 = AmgT<double>{};
+    b->amg32 = AmgT<float>{};
     b->run_id = ++ctx->run_id;
     const double t_start = now_ms();
     try {
@@ -933,6 +935,40 @@ int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *b, double *x, double *
         if (k_out) *k_out = b->k_last;
         return REMO_OK;
     } catch (const std::exception &ex) {
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out) {
+    if (!ctx) return REMO_ERR_ARG;
+    if (!b || !b->has_system || b->run_id != ctx->run_id || k < 1 || k > REMO_MAX_RHS) return fail(ctx, REMO_ERR_ARG, "bad argument");
+    if (b->amg64.levels < 2 || (fp32 && b->amg32.levels < 2)) return fail(ctx, REMO_ERR_ARG, "the last run on this batch built no multigrid hierarchy");
+    if (k > b->amg64.kmax) return fail(ctx, REMO_ERR_ARG, "more columns than the hierarchy's level vectors hold (the batch's right-hand sides per chunk)");
+    const int64_t nv = b->amg64.lev[0].n;
+    if (nv_out) *nv_out = nv;
+    if (!r || !z) return REMO_OK;
+    double *dr = nullptr, *dz = nullptr, *dpart = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dr), sizeof(double) * (nv * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dz), sizeof(double) * (nv * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dpart), sizeof(double) * kMaxPartialBlocks * 8));
+        HIP_TRY(hipMemcpy(dr, r, sizeof(double) * nv * k, hipMemcpyHostToDevice));
+        const int nb = cheb_grid(nv);
+        if (fp32) launch_amg_cycle<float, double>(b->amg32, k, 0, (const double *)dr, dz, dpart, nb, (const double *)nullptr, ctx->stream);
+        else launch_amg_cycle<double, double>(b->amg64, k, 0, (const double *)dr, dz, dpart, nb, (const double *)nullptr, ctx->stream);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<double> dinv(static_cast<size_t>(nv));
+        HIP_TRY(hipMemcpy(z, dz, sizeof(double) * nv * k, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dinv.data(), b->d_dinv, sizeof(double) * nv, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < nv; ++i)
+            for (int c = 0; c < k; ++c) z[i * k + c] *= dinv[static_cast<size_t>(i)];   // the cycle stores z / dinv for the direction launch
+        (void)hipFree(dr); (void)hipFree(dz); (void)hipFree(dpart);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (dr) (void)hipFree(dr);
+        if (dz) (void)hipFree(dz);
+        if (dpart) (void)hipFree(dpart);
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
 }

@@ -203,6 +203,20 @@ class Batch:
             raise RemoError(rc, self.ctx.last_error())
         return x, f
 
+    def apply_vertex_solver(self, r, fp32=False):
+        """z = one multigrid cycle of the last run's hierarchy applied to r [nv, k] (remo_batch_apply_coarse); nv = rows of the
+        P1 block.  Raises when the last run used the Chebyshev polynomial."""
+        nv = C.c_int64(0)
+        rc = self._L.remo_batch_apply_coarse(self.ctx._h, self._h, 1, None, None, 1 if fp32 else 0, C.byref(nv))
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        r = np.ascontiguousarray(np.asarray(r, float).reshape(nv.value, -1))
+        z = np.zeros_like(r)
+        rc = self._L.remo_batch_apply_coarse(self.ctx._h, self._h, r.shape[1], ptr(r, C.c_double), ptr(z, C.c_double), 1 if fp32 else 0, C.byref(nv))
+        if rc != 0:
+            raise RemoError(rc, self.ctx.last_error())
+        return z
+
     def true_relres(self):
         """sqrt(<C r, r> / <C f, f>) per column with r = f - A x recomputed from the solution (one device SpMM), C = Jacobi:
         what the recurrence residual of the PCG claims, measured."""

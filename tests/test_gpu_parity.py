@@ -608,3 +608,52 @@ def test_multigrid_cycle_is_reproducible_and_cuts_the_steps_on_a_config2_batch(g
     assert np.array_equal(u1, u2) and s1 == s2
     assert np.max(np.abs(u1 - uc) / np.abs(uc)) < 1e-7
     assert s1 <= 0.75 * sc
+
+
+@pytest.mark.gpu
+def test_multigrid_cycle_is_a_symmetric_positive_convergent_operator(mesh2d, gpu_ctx):
+    """One cycle C of the hierarchy, applied through the inspection hook: symmetric (r1' C r2 = r2' C r1 to rounding: the PCG needs
+    a fixed symmetric preconditioner), positive, and a convergent iteration for the P1 block by itself - the energy norm of the
+    error shrinks by at least a third per cycle on random vectors (the block comes from remo_batch_get_system); the fp32 image
+    is the same operator to fp32 rounding."""
+    import scipy.sparse as sp
+    from remo3d_amd import solver
+    b = gpu_ctx.batch(mesh2d, SIGMA3, SRC, EVAL)
+    try:
+        rc = b.run(solver.make_opts(rtol=1e-10, coarse="amg"))
+        assert rc == 0 and b.stats["coarse_used"] == 2
+        rowptr, col, val, dinv, freeid = b.system()
+        n = len(rowptr) - 1
+        A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        rng = np.random.default_rng(5)
+        # the block size: ask with a first call
+        import ctypes as C
+        nvc = C.c_int64(0)
+        assert b._L.remo_batch_apply_coarse(b.ctx._h, b._h, 1, None, None, 0, C.byref(nvc)) == 0
+        nv = nvc.value
+        Avv = A[:nv, :nv].tocsr()
+        R = rng.standard_normal((nv, 3))
+        Z = b.apply_vertex_solver(R)
+        G = R.T @ Z
+        assert np.max(np.abs(G - G.T)) <= 1e-11 * np.max(np.abs(G))
+        assert np.all(np.diag(G) > 0)
+        E = rng.standard_normal((nv, 3))
+        E1 = E - b.apply_vertex_solver(Avv @ E)
+        before = np.sqrt(np.einsum("ik,ik->k", E, Avv @ E))
+        after = np.sqrt(np.einsum("ik,ik->k", E1, Avv @ E1))
+        print("energy-norm contraction of one cycle:", after / before)
+        assert np.all(after < 0.67 * before)
+        Z32 = b.apply_vertex_solver(R, fp32=True)
+        assert np.max(np.abs(Z32 - Z)) <= 1e-4 * np.max(np.abs(Z))
+        # three columns and one: the same operator column by column; more columns than the batch has right-hand sides are refused
+        Z1 = b.apply_vertex_solver(R[:, 2:3])
+        assert np.max(np.abs(Z[:, 2:3] - Z1)) <= 1e-13 * np.max(np.abs(Z1))
+        with pytest.raises(solver.RemoError):
+            b.apply_vertex_solver(rng.standard_normal((nv, 8)))
+        # a run with the polynomial leaves no hierarchy behind
+        rc = b.run(solver.make_opts(rtol=1e-10, coarse="chebyshev"))
+        assert rc == 0
+        with pytest.raises(solver.RemoError):
+            b.apply_vertex_solver(R)
+    finally:
+        b.close()

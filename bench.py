@@ -361,7 +361,7 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8,2D-BM1/2ctx:8",
+    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8,2D-BM1/2ctx:8,2D-BM1/mixed:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
                          "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size; '2D-BM1' = BASELINE configs[1], "
                          "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block, '/2ctx' = two contexts (streams, host threads) share the batches), reported in the `sizes` array; '' = none")

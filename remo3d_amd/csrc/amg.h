@@ -40,7 +40,7 @@ template <class T> struct AmgT {
 // enqueued on s; the function synchronises a few times per level to read sizes back.  Returns false (with the reason) when
 // the hierarchy cannot be built (a row too long for the LDS tables, no coarsening, arena exhausted): the caller keeps the
 // Chebyshev polynomial.
-bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax,
+bool amg_setup(Arena &ar, hipStream_t s, int dim, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax,
                AmgT<double> &out, std::string &why);
 // fp32 image of a hierarchy (values converted, patterns shared, own vectors) for the inner solver of the mixed mode
 void amg_to_float(Arena &ar, hipStream_t s, const AmgT<double> &in, int kmax, AmgT<float> &out);

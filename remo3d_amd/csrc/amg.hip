@@ -220,7 +220,7 @@ template <int PASS, int SLOTS>
 __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__restrict__ xrp, const int32_t *__restrict__ xc, const double *__restrict__ xv,
                                                 const int32_t *__restrict__ yrp, const int32_t *__restrict__ yc, const double *__restrict__ yv,
                                                 int32_t *__restrict__ cnt, const int32_t *__restrict__ crp, int32_t *__restrict__ cc,
-                                                double *__restrict__ cv, int32_t *flag) {
+                                                double *__restrict__ cv, int32_t *flag) {   // PASS 1: crp has been clamped to the capacity of cc / cv (k_clamp_rowptr)
     __shared__ int32_t keys[4][SLOTS];
     __shared__ int32_t list[4][SLOTS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -281,6 +281,8 @@ __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__res
             wave_sync();
         }
     const int64_t off = crp[row];
+    const int room = int(crp[row + 1] - crp[row]);   // < c only when the product outgrew its arrays (flagged by k_clamp_rowptr): stay inside them
+    if (c > room) c = room;
     for (int t = lane; t < c; t += 64) {
         const int32_t j = L[t];
         double acc = 0.0;
@@ -293,6 +295,15 @@ __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__res
         cc[off + t] = j;
         cv[off + t] = acc;
     }
+}
+
+// row pointers of a product whose arrays were allocated by an upper bound, before the size is known on the host: anything
+// beyond the capacity is cut off (rows stay inside the arrays, consumers never index past them) and flagged
+__global__ void __launch_bounds__(256) k_clamp_rowptr(int64_t n, int32_t *__restrict__ rowptr, int32_t capacity, int32_t *flag) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int32_t v = rowptr[i];
+    if (v > capacity) { rowptr[i] = capacity; if (i == n) atomicOr(flag, 2); }
 }
 
 // ---- transpose without a device-wide sort: count, scan, scatter in any order, then every row sorted by a wave in LDS --------
@@ -592,10 +603,12 @@ struct Csr {
     double *val = nullptr;
 };
 
-// variant 1: a wave per row with 128 hash slots, 2: with 512.  `hint` remembers the variant that worked for this product of this
-// level the last time (process-wide; meshes of a sweep look alike).  (Variant 0 was one LANE per row with a private sorted
-// list of at most 32 columns for the short rows of S P0 and A P: 230 us per launch against 70 - private arrays with dynamic
-// indices live in scratch memory; removed.)
+// Products without a read-back.  The result arrays are allocated by an upper bound (`cap` entries), the row pointers come
+// from the count pass and a scan on the device and are clamped to the capacity; overflowing hash tables (bit 1) or arrays
+// (bit 2) raise the product's own flag slot, which the host reads at the NEXT point where it has to wait anyway.
+// variant 1: a wave per row with 128 hash slots, 2: with 512; remembered per kind of matrix, level and product (process-wide;
+// the meshes of a sweep look alike).  (Variant 0 was one LANE per row with a private sorted list of at most 32 columns for the
+// short rows of S P0 and A P: 230 us per launch against 70 - private arrays with dynamic indices live in scratch memory; removed.)
 template <int PASS>
 void launch_product(int variant, hipStream_t s, const Csr &X, const Csr &Y, int32_t *cnt, const int32_t *crp, int32_t *cc, double *cv, int32_t *d_over) {
     if (variant <= 1)
@@ -604,164 +617,210 @@ void launch_product(int variant, hipStream_t s, const Csr &X, const Csr &Y, int3
         hipLaunchKernelGGL((k_spgemm<PASS, 512>), dim3(grid_rows(X.n, 4)), dim3(256), 0, s, X.n, X.rowptr, X.col, X.val, Y.rowptr, Y.col, Y.val, cnt, crp, cc, cv, d_over);
 }
 
-int64_t spgemm(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const Csr &Y, int32_t *d_flag, Csr &C, std::atomic<int> &hint, int first_variant) {
+void spgemm_async(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const Csr &Y, int64_t cap, int variant, int32_t *d_over, Csr &C) {
+    if (cap > INT_MAX - 8) cap = INT_MAX - 8;
     C.n = X.n;
+    C.nnz = cap;   // upper bound; the exact count is rowptr[n] on the device
     C.rowptr = permanent ? ar.lo<int32_t>(size_t(X.n) + 2) : ar.hi<int32_t>(size_t(X.n) + 2);
-    int32_t *d_over = d_flag + 40;   // overflow of the product's tables, apart from the setup's other flags
-    int start = hint.load(std::memory_order_relaxed);
-    if (start < first_variant) start = first_variant;
-    for (int variant = start; variant <= 2; ++variant) {
-        const size_t mark = ar.hi_mark();
-        int32_t *cnt = ar.hi<int32_t>(size_t(X.n) + 2);
-        HIP_OK(hipMemsetAsync(d_over, 0, sizeof(int32_t), s));
-        launch_product<0>(variant, s, X, Y, cnt, nullptr, nullptr, nullptr, d_over);
-        scan_counts(ar, s, X.n, cnt, C.rowptr);
-        int32_t h[2] = {0, 0};
-        HIP_OK(hipMemcpyAsync(&h[0], C.rowptr + X.n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipMemcpyAsync(&h[1], d_over, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        ar.hi_release(mark);
-        if (h[1] != 0) continue;
-        if (h[0] <= 0 || h[0] == INT_MAX) return -1;
-        hint.store(variant, std::memory_order_relaxed);
-        C.nnz = h[0];
-        C.col = permanent ? ar.lo<int32_t>(size_t(C.nnz) + 2) : ar.hi<int32_t>(size_t(C.nnz) + 2);
-        C.val = permanent ? ar.lo<double>(size_t(C.nnz) + 2) : ar.hi<double>(size_t(C.nnz) + 2);
-        launch_product<1>(variant, s, X, Y, nullptr, C.rowptr, C.col, C.val, d_over);
-        return C.nnz;
-    }
-    return -1;
+    int32_t *cnt = ar.hi<int32_t>(size_t(X.n) + 2);   // scratch of the level
+    launch_product<0>(variant, s, X, Y, cnt, nullptr, nullptr, nullptr, d_over);
+    scan_counts(ar, s, X.n, cnt, C.rowptr);
+    hipLaunchKernelGGL(k_clamp_rowptr, dim3(grid_rows(X.n + 1, 256)), dim3(256), 0, s, X.n, C.rowptr, int32_t(cap), d_over);
+    C.col = permanent ? ar.lo<int32_t>(size_t(cap) + 2) : ar.hi<int32_t>(size_t(cap) + 2);
+    C.val = permanent ? ar.lo<double>(size_t(cap) + 2) : ar.hi<double>(size_t(cap) + 2);
+    launch_product<1>(variant, s, X, Y, nullptr, C.rowptr, C.col, C.val, d_over);
 }
 
-std::atomic<int> g_product_hint[kAmgMaxLevels][3];   // zero-initialised: start with the cheapest variant
+std::atomic<int> g_product_hint[2][kAmgMaxLevels][3];   // [2D | 3D matrices][level][S P0, A P, R (A P)]; 0 / 1: 128 slots, 2: 512
+std::atomic<int> g_ap_room[2];                          // log2 of the extra room of A P beyond 4 nnz(A) (0 .. 3)
+constexpr int kFlagSlots = 64;                          // [0] setup flags, [1] scratch counter, [8 + 3 level + product] product flags
+
+// one attempt: 0 = built, 1 = a product outgrew its tables or arrays (the hints have been raised: try again), -1 = failed
+int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax, AmgT<double> &H,
+              std::string &why) {
+    H = AmgT<double>{};
+    int32_t *d_flag = ar.lo<int32_t>(kFlagSlots);
+    unsigned long long *d_bound = ar.lo<unsigned long long>(kAmgMaxLevels + 1);
+    HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int32_t) * kFlagSlots, s));
+    HIP_OK(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long) * (kAmgMaxLevels + 1), s));
+    int32_t h_flags[kFlagSlots] = {};
+    int32_t h_nnz_a[kAmgMaxLevels] = {}, h_nnz_p[kAmgMaxLevels] = {};
+    const int32_t *d_nnz_a[kAmgMaxLevels] = {}, *d_nnz_p[kAmgMaxLevels] = {};   // where the exact counts live on the device
+    // looks at the flags read back so far; products of the levels below `upto`
+    auto check = [&](int upto) -> int {
+        int again = 0;   // the products first: a cut-off product leaves rows without a diagonal behind, which is then flagged as well
+        for (int l = 0; l < upto; ++l)
+            for (int p = 0; p < 3; ++p) {
+                const int f = h_flags[8 + 3 * l + p];
+                if (f == 0) continue;
+                if (f & 1) {   // hash tables
+                    if (g_product_hint[hs][l][p].load() >= 2) { why = "a product row with more than 256 distinct columns"; return -1; }
+                    g_product_hint[hs][l][p].store(2);
+                    again = 1;
+                }
+                if (f & 2) {   // arrays
+                    if (p != 1 || g_ap_room[hs].load() >= 3) { why = "a product outgrew its arrays"; return -1; }
+                    g_ap_room[hs].fetch_add(1);
+                    again = 1;
+                }
+            }
+        if (again) return 1;
+        if (h_flags[0] != 0) {
+            why = "setup raised flag " + std::to_string(h_flags[0]) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort)";
+            return -1;
+        }
+        return 0;
+    };
+    // level 0: compact copy of the leading block
+    Csr A;
+    A.n = nv;
+    A.rowptr = ar.lo<int32_t>(size_t(nv) + 2);
+    {
+        const size_t mark = ar.hi_mark();
+        int32_t *cnt = ar.hi<int32_t>(size_t(nv) + 2);
+        hipLaunchKernelGGL((k_block_copy<0>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, cnt, (const int32_t *)nullptr,
+                           (int32_t *)nullptr, (double *)nullptr);
+        scan_counts(ar, s, nv, cnt, A.rowptr);
+        int32_t h = 0;
+        HIP_OK(hipMemcpyAsync(&h, A.rowptr + nv, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        ar.hi_release(mark);
+        if (h <= 0 || h == INT_MAX) { why = "empty vertex block"; return -1; }
+        A.nnz = h;
+        h_nnz_a[0] = h;
+        A.col = ar.lo<int32_t>(size_t(h) + 2);
+        A.val = ar.lo<double>(size_t(h) + 2);
+        hipLaunchKernelGGL((k_block_copy<1>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, (int32_t *)nullptr,
+                           (const int32_t *)A.rowptr, A.col, A.val);
+    }
+    int L = 0;
+    for (;;) {
+        AmgLevelT<double> &lv = H.lev[L];
+        const int64_t n = A.n;
+        lv.n = n; lv.rowptr = A.rowptr; lv.col = A.col; lv.val = A.val;
+        double *dinv = ar.lo<double>(size_t(n) + 2);
+        lv.dinv = dinv;
+        lv.z = ar.lo<double>(size_t(n) * kmax + 2);
+        lv.z2 = ar.lo<double>(size_t(n) * kmax + 2);
+        lv.t = ar.lo<double>(size_t(n) * kmax + 2);
+        if (L > 0) lv.r = ar.lo<double>(size_t(n) * kmax + 2);
+        const int g = grid_rows(n, 256);
+        hipLaunchKernelGGL(k_level_diag, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, d_bound + L, d_flag);
+        if (n <= kAmgDenseMax) {   // coarsest: dense inverse
+            double *inv = ar.lo<double>(size_t(n) * n + 2);
+            hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(256), 0, s, int(n), A.rowptr, A.col, A.val, inv, d_flag);
+            H.inv = inv;
+            H.levels = L + 1;
+            break;
+        }
+        if (L + 1 >= kAmgMaxLevels) { why = "too many levels"; return -1; }
+        // ---- aggregation ----
+        const size_t mark = ar.hi_mark();   // the scratch of a level is reused by the next one: the stream orders the kernels
+        uint64_t *tup = ar.hi<uint64_t>(size_t(n) + 2), *m1 = ar.hi<uint64_t>(size_t(n) + 2);
+        int32_t *isroot = ar.hi<int32_t>(size_t(n) + 2), *id = ar.hi<int32_t>(size_t(n) + 2);
+        int32_t *agg1 = ar.hi<int32_t>(size_t(n) + 2), *agg = ar.hi<int32_t>(size_t(n) + 2);
+        hipLaunchKernelGGL(k_mis_init, dim3(g), dim3(256), 0, s, n, tup);
+        for (int it = 0; it < 10; ++it) {   // a fixed number of iterations, no read-back (460 of 80 k nodes are open after six, none after twelve); k_mis_finish settles stragglers
+            hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
+            hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1, d_flag + 1);
+        }
+        hipLaunchKernelGGL(k_mis_finish, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
+        hipLaunchKernelGGL(k_mis_flags, dim3(g), dim3(256), 0, s, n, m1, isroot);
+        scan_counts(ar, s, n, isroot, id);
+        hipLaunchKernelGGL(k_agg_near, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, m1, id, agg1);
+        hipLaunchKernelGGL(k_agg_far, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, agg1, agg);
+        // ---- the level's ONE wait: number of aggregates, spectrum bound, everything flagged so far, exact size of this level's matrix
+        int32_t h_nc = 0;
+        unsigned long long h_bound = 0;
+        HIP_OK(hipMemcpyAsync(&h_nc, id + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(&h_bound, d_bound + L, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipMemcpyAsync(h_flags, d_flag, sizeof(int32_t) * kFlagSlots, hipMemcpyDeviceToHost, s));
+        if (L > 0) HIP_OK(hipMemcpyAsync(&h_nnz_a[L], A.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        const int verdict = check(L);
+        if (verdict != 0) return verdict;
+        double lmax;
+        std::memcpy(&lmax, &h_bound, sizeof lmax);
+        const int64_t nnz_a = h_nnz_a[L];
+        if (getenv("REMO_AMG_DEBUG")) fprintf(stderr, "amg level %d: n %lld nnz %lld -> %d aggregates, lmax %.3f\n", L, (long long)n, (long long)nnz_a, h_nc, lmax);
+        if (!(lmax > 0.0) || !std::isfinite(lmax) || nnz_a <= 0) { why = "level operator without a spectrum bound"; return -1; }
+        lv.omega = 1.6 / lmax;
+        lv.nnz = nnz_a;
+        const int64_t nc = h_nc;
+        if (nc <= 0 || nc * 10 > n * 8) { why = "no coarsening"; return -1; }
+        // ---- P = (I - 4/(3 lmax) D^-1 A) P0: at most as many entries as A ----
+        Csr S = A, P0;
+        S.val = ar.hi<double>(size_t(nnz_a) + 2);
+        P0.n = n; P0.nnz = n;
+        P0.rowptr = ar.hi<int32_t>(size_t(n) + 2); P0.col = ar.hi<int32_t>(size_t(n) + 2); P0.val = ar.hi<double>(size_t(n) + 2);
+        hipLaunchKernelGGL(k_smoothing_factor, dim3(grid_rows(n + 1, 256)), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, d_bound + L, S.val,
+                           agg, P0.rowptr, P0.col, P0.val);
+        int32_t *pf = d_flag + 8 + 3 * L;
+        Csr P;
+        spgemm_async(ar, true, s, S, P0, nnz_a, g_product_hint[hs][L][0].load(), pf + 0, P);
+        lv.p_rowptr = P.rowptr; lv.p_col = P.col; lv.p_val = P.val;
+        d_nnz_p[L] = P.rowptr + n;
+        // ---- R = P^T: count the entries of every column, scan, scatter (any order), sort every row of R by its column = row of P ----
+        Csr R;
+        R.n = nc; R.nnz = nnz_a;
+        R.rowptr = ar.lo<int32_t>(size_t(nc) + 2); R.col = ar.lo<int32_t>(size_t(nnz_a) + 2); R.val = ar.lo<double>(size_t(nnz_a) + 2);
+        {
+            int32_t *tcnt = ar.hi<int32_t>(size_t(nc) + 2), *cursor = ar.hi<int32_t>(size_t(nc) + 2);
+            HIP_OK(hipMemsetAsync(tcnt, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
+            HIP_OK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
+            hipLaunchKernelGGL(k_tr_count, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, tcnt);
+            scan_counts(ar, s, nc, tcnt, R.rowptr);
+            hipLaunchKernelGGL(k_tr_fill, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, P.val, R.rowptr, cursor, R.col, R.val);
+            hipLaunchKernelGGL(k_tr_sort, dim3(grid_rows(nc, 4)), dim3(256), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
+        }
+        lv.r_rowptr = R.rowptr; lv.r_col = R.col; lv.r_val = R.val;
+        // ---- A' = R (A P): A P in scratch with room for (4 << room) nnz(A) entries, A' at most as many entries as A ----
+        Csr AP, Ac;
+        spgemm_async(ar, false, s, A, P, (nnz_a * 4) << g_ap_room[hs].load(), g_product_hint[hs][L][1].load(), pf + 1, AP);
+        spgemm_async(ar, true, s, R, AP, nnz_a, g_product_hint[hs][L][2].load(), pf + 2, Ac);
+        ar.hi_release(mark);
+        A = Ac;
+        A.n = nc;
+        ++L;
+    }
+    // ---- the last wait: flags of the last level's products and of the dense inverse, exact sizes for the fp32 image ----
+    HIP_OK(hipMemcpyAsync(h_flags, d_flag, sizeof(int32_t) * kFlagSlots, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&h_nnz_a[L], A.rowptr + A.n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    for (int l = 0; l < L; ++l) HIP_OK(hipMemcpyAsync(&h_nnz_p[l], d_nnz_p[l], sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    const int verdict = check(L);
+    if (verdict != 0) return verdict;
+    H.lev[L].nnz = h_nnz_a[L];
+    for (int l = 0; l < L; ++l) H.lev[l].nnz_p = h_nnz_p[l];
+    (void)d_nnz_a;
+    H.launches = 4 * (H.levels - 1) + 1;
+    H.kmax = kmax;
+    return 0;
+}
 
 }  // namespace
 
-bool amg_setup(Arena &ar, hipStream_t s, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax, AmgT<double> &H,
+bool amg_setup(Arena &ar, hipStream_t s, int dim, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax, AmgT<double> &H,
                std::string &why) {
     H = AmgT<double>{};
     if (nv <= kAmgDenseMax) { why = "vertex block too small"; return false; }
-    const size_t hi0 = ar.hi_mark();
+    const int hs = dim == 3 ? 1 : 0;   // what earlier batches taught about the products: per kind of matrix
+    const size_t hi0 = ar.hi_mark(), lo0 = ar.lo_off;
     try {
-        int32_t *d_flag = ar.lo<int32_t>(64);               // [0] flags, [1 ..] undecided counters
-        unsigned long long *d_bound = ar.lo<unsigned long long>(kAmgMaxLevels + 1);
-        HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int32_t) * 64, s));
-        HIP_OK(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long) * (kAmgMaxLevels + 1), s));
-        // level 0: compact copy of the leading block
-        Csr A;
-        A.n = nv;
-        A.rowptr = ar.lo<int32_t>(size_t(nv) + 2);
-        {
-            const size_t mark = ar.hi_mark();
-            int32_t *cnt = ar.hi<int32_t>(size_t(nv) + 2);
-            hipLaunchKernelGGL((k_block_copy<0>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, cnt, (const int32_t *)nullptr,
-                               (int32_t *)nullptr, (double *)nullptr);
-            scan_counts(ar, s, nv, cnt, A.rowptr);
-            int32_t h = 0;
-            HIP_OK(hipMemcpyAsync(&h, A.rowptr + nv, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIP_OK(hipStreamSynchronize(s));
-            ar.hi_release(mark);
-            if (h <= 0 || h == INT_MAX) { why = "empty vertex block"; return false; }
-            A.nnz = h;
-            A.col = ar.lo<int32_t>(size_t(h) + 2);
-            A.val = ar.lo<double>(size_t(h) + 2);
-            hipLaunchKernelGGL((k_block_copy<1>), dim3(grid_rows(nv, 256)), dim3(256), 0, s, nv, rowptr, col, val, (int32_t *)nullptr,
-                               (const int32_t *)A.rowptr, A.col, A.val);
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            ar.hi_release(hi0);
+            ar.lo_off = lo0;               // a repeated attempt reuses the memory of the failed one (the stream orders the kernels)
+            const int rc = amg_build(ar, s, hs, nv, rowptr, col, val, kmax, H, why);
+            ar.hi_release(hi0);
+            if (rc == 0) return true;
+            if (rc < 0) break;
         }
-        int L = 0;
-        for (;;) {
-            AmgLevelT<double> &lv = H.lev[L];
-            const int64_t n = A.n;
-            lv.n = n; lv.nnz = A.nnz; lv.rowptr = A.rowptr; lv.col = A.col; lv.val = A.val;
-            double *dinv = ar.lo<double>(size_t(n) + 2);
-            lv.dinv = dinv;
-            lv.z = ar.lo<double>(size_t(n) * kmax + 2);
-            lv.z2 = ar.lo<double>(size_t(n) * kmax + 2);
-            lv.t = ar.lo<double>(size_t(n) * kmax + 2);
-            if (L > 0) lv.r = ar.lo<double>(size_t(n) * kmax + 2);
-            const int g = grid_rows(n, 256);
-            hipLaunchKernelGGL(k_level_diag, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, d_bound + L, d_flag);
-            if (n <= kAmgDenseMax) {   // coarsest: dense inverse
-                double *inv = ar.lo<double>(size_t(n) * n + 2);
-                hipLaunchKernelGGL(k_dense_inverse, dim3(1), dim3(256), 0, s, int(n), A.rowptr, A.col, A.val, inv, d_flag);
-                H.inv = inv;
-                H.levels = L + 1;
-                break;
-            }
-            if (L + 1 >= kAmgMaxLevels) { why = "too many levels"; ar.hi_release(hi0); return false; }
-            // ---- aggregation ----
-            const size_t mark = ar.hi_mark();
-            uint64_t *tup = ar.hi<uint64_t>(size_t(n) + 2), *m1 = ar.hi<uint64_t>(size_t(n) + 2);
-            int32_t *isroot = ar.hi<int32_t>(size_t(n) + 2), *id = ar.hi<int32_t>(size_t(n) + 2);
-            int32_t *agg1 = ar.hi<int32_t>(size_t(n) + 2), *agg = ar.hi<int32_t>(size_t(n) + 2);
-            hipLaunchKernelGGL(k_mis_init, dim3(g), dim3(256), 0, s, n, tup);
-            unsigned long long h_bound = 0;
-            int32_t h_flag = 0;
-            for (int it = 0; it < 10; ++it) {   // a fixed number of iterations, no read-back (460 of 80 k nodes are open after six, none after twelve); k_mis_finish settles stragglers
-                hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
-                hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1, d_flag + 1);
-            }
-            hipLaunchKernelGGL(k_mis_finish, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
-            hipLaunchKernelGGL(k_mis_flags, dim3(g), dim3(256), 0, s, n, m1, isroot);
-            scan_counts(ar, s, n, isroot, id);
-            hipLaunchKernelGGL(k_agg_near, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, m1, id, agg1);
-            hipLaunchKernelGGL(k_agg_far, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, A.val, agg1, agg);
-            int32_t h_nc = 0;
-            HIP_OK(hipMemcpyAsync(&h_nc, id + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIP_OK(hipMemcpyAsync(&h_bound, d_bound + L, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            HIP_OK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            // ---- P = (I - 4/(3 lmax) D^-1 A) P0 ----
-            Csr S = A, P0;
-            S.val = ar.hi<double>(size_t(A.nnz) + 2);
-            P0.n = n; P0.nnz = n;
-            P0.rowptr = ar.hi<int32_t>(size_t(n) + 2); P0.col = ar.hi<int32_t>(size_t(n) + 2); P0.val = ar.hi<double>(size_t(n) + 2);
-            hipLaunchKernelGGL(k_smoothing_factor, dim3(grid_rows(n + 1, 256)), dim3(256), 0, s, n, A.rowptr, A.col, A.val, dinv, d_bound + L, S.val,
-                               agg, P0.rowptr, P0.col, P0.val);
-            HIP_OK(hipStreamSynchronize(s));
-            double lmax;
-            std::memcpy(&lmax, &h_bound, sizeof lmax);
-            if (getenv("REMO_AMG_DEBUG")) fprintf(stderr, "amg level %d: n %lld nnz %lld -> %d aggregates, lmax %.3f\n", L, (long long)n, (long long)A.nnz, h_nc, lmax);
-            if (h_flag != 0 || !(lmax > 0.0) || !std::isfinite(lmax)) { why = "level setup raised flag " + std::to_string(h_flag) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort) or lost its spectrum bound"; ar.hi_release(hi0); return false; }
-            lv.omega = 1.6 / lmax;
-            const int64_t nc = h_nc;
-            if (nc <= 0 || nc * 10 > n * 8) { why = "no coarsening"; ar.hi_release(hi0); return false; }
-            Csr P;
-            if (spgemm(ar, true, s, S, P0, d_flag, P, g_product_hint[L][0], 1) < 0) { why = "prolongator row too long"; ar.hi_release(hi0); return false; }
-            lv.p_rowptr = P.rowptr; lv.p_col = P.col; lv.p_val = P.val; lv.nnz_p = P.nnz;
-            // ---- R = P^T ----
-            Csr R;
-            R.n = nc; R.nnz = P.nnz;
-            R.rowptr = ar.lo<int32_t>(size_t(nc) + 2); R.col = ar.lo<int32_t>(size_t(P.nnz) + 2); R.val = ar.lo<double>(size_t(P.nnz) + 2);
-            {   // count the entries of every column, scan, scatter (any order), sort every row of R by its column = row of P
-                int32_t *tcnt = ar.hi<int32_t>(size_t(nc) + 2), *cursor = ar.hi<int32_t>(size_t(nc) + 2);
-                HIP_OK(hipMemsetAsync(tcnt, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
-                HIP_OK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t(nc) + 2), s));
-                hipLaunchKernelGGL(k_tr_count, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, tcnt);
-                scan_counts(ar, s, nc, tcnt, R.rowptr);
-                hipLaunchKernelGGL(k_tr_fill, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, P.val, R.rowptr, cursor, R.col, R.val);
-                hipLaunchKernelGGL(k_tr_sort, dim3(grid_rows(nc, 4)), dim3(256), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
-            }
-            lv.r_rowptr = R.rowptr; lv.r_col = R.col; lv.r_val = R.val;
-            // ---- A' = R (A P) ----
-            Csr AP, Ac;
-            if (spgemm(ar, false, s, A, P, d_flag, AP, g_product_hint[L][1], 1) < 0) { why = "A P row too long"; ar.hi_release(hi0); return false; }
-            if (spgemm(ar, true, s, R, AP, d_flag, Ac, g_product_hint[L][2], 1) < 0) { why = "coarse row too long"; ar.hi_release(hi0); return false; }
-            HIP_OK(hipStreamSynchronize(s));   // the scratch of this level is released next
-            ar.hi_release(mark);
-            A = Ac;
-            A.n = nc;
-            ++L;
-        }
-        int32_t h_flag = 0;
-        HIP_OK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        ar.hi_release(hi0);
-        if (h_flag != 0) { why = "setup raised flag " + std::to_string(h_flag) + " (1 diagonal, 2 dense pivot, 4 a row of R beyond the LDS sort)"; return false; }
-        H.launches = 4 * (H.levels - 1) + 1;
-        H.kmax = kmax;
-        return true;
+        if (why.empty()) why = "the products did not fit after several attempts";
+        H = AmgT<double>{};
+        return false;
     } catch (const std::exception &ex) {
         ar.hi_release(hi0);
+        H = AmgT<double>{};
         why = ex.what();
         return false;
     }

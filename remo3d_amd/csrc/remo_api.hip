@@ -664,7 +664,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         }
         if (two_level && want_amg) {   // multigrid cycle on the vertex block instead of the polynomial (amg.hip)
             std::string why;
-            if (amg_setup(ctx->ar, s, buf.nv_coarse, sy.rowptr, sy.col, d_val, kmax, b->amg64, why)) buf.amg = &b->amg64;
+            if (amg_setup(ctx->ar, s, dim, buf.nv_coarse, sy.rowptr, sy.col, d_val, kmax, b->amg64, why)) buf.amg = &b->amg64;
             else if (o.coarse == 2 || g_amg == 2) return fail(ctx, REMO_ERR_NUMERIC, "multigrid hierarchy of the vertex block: " + why);
         }
         bool amg32_ready = false;

@@ -176,6 +176,28 @@ def cpu_baseline(work, rtol, cores=None):
                        "core like the reference's farm, not the reference binary"), res[0][0]
 
 
+def box_stream(device):
+    """What THIS box streams from HBM: a 1 GiB read (torch sum over fp32) and a 1 GiB device-to-device copy, HIP events, best of 5.
+    The SpMM's time differs by up to 20 % between boxes of the pool; this figure says how much of that is the box."""
+    try:
+        import torch
+        dev = torch.device("cuda", device)
+        x = torch.ones(1 << 28, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        best_r, best_c = 1e9, 1e9
+        for _ in range(6):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(); x.sum(); e1.record(); y.copy_(x); e2.record()
+            torch.cuda.synchronize(dev)
+            best_r = min(best_r, e0.elapsed_time(e1)); best_c = min(best_c, e1.elapsed_time(e2))
+        nbytes = x.numel() * 4
+        del x, y
+        torch.cuda.empty_cache()
+        return dict(stream_read_GBs=nbytes / best_r * 1e-6, stream_copy_GBs=2 * nbytes / best_c * 1e-6, note="1 GiB torch sum / copy_, best of 6")
+    except Exception as ex:   # the probe is context, never a reason to lose the line
+        return dict(error="%s: %s" % (type(ex).__name__, ex))
+
+
 def pmc_traffic(workload, n_free, nnz):
     """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this exact workload
     (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
@@ -520,6 +542,8 @@ def main():
     else:
         out["cpu_baseline"] = None
     runner.close()
+    if extras:
+        out["box"] = box_stream(local)
 
     sizes = []
     for name, w2 in extra_wl:

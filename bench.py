@@ -177,23 +177,17 @@ def cpu_baseline(work, rtol, cores=None):
 
 
 def box_stream(device):
-    """What THIS box streams from HBM: a 1 GiB read (torch sum over fp32) and a 1 GiB device-to-device copy, HIP events, best of 5.
-    The SpMM's time differs by up to 20 % between boxes of the pool; this figure says how much of that is the box."""
+    """What THIS box streams from HBM (remo_debug_stream): a 1 GiB read through a plain summing kernel and a 1 GiB device-to-device
+    copy, HIP events, best of six.  The SpMM's time differs by up to 20 % between boxes of the pool; this says how much is the box."""
+    import ctypes as C
+    from remo3d_amd import _lib, solver
     try:
-        import torch
-        dev = torch.device("cuda", device)
-        x = torch.ones(1 << 28, dtype=torch.float32, device=dev)
-        y = torch.empty_like(x)
-        best_r, best_c = 1e9, 1e9
-        for _ in range(6):
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record(); x.sum(); e1.record(); y.copy_(x); e2.record()
-            torch.cuda.synchronize(dev)
-            best_r = min(best_r, e0.elapsed_time(e1)); best_c = min(best_c, e1.elapsed_time(e2))
-        nbytes = x.numel() * 4
-        del x, y
-        torch.cuda.empty_cache()
-        return dict(stream_read_GBs=nbytes / best_r * 1e-6, stream_copy_GBs=2 * nbytes / best_c * 1e-6, note="1 GiB torch sum / copy_, best of 6")
+        with solver.Context(device) as ctx:
+            r, c = C.c_double(0), C.c_double(0)
+            rc = _lib.load().remo_debug_stream(ctx._h, 1 << 30, C.byref(r), C.byref(c))
+            if rc != 0:
+                return dict(error=ctx.last_error())
+            return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, note="1 GiB, 16-byte loads in a summing kernel / hipMemcpy device to device (read + write), best of 6")
     except Exception as ex:   # the probe is context, never a reason to lose the line
         return dict(error="%s: %s" % (type(ex).__name__, ex))
 

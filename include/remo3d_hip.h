@@ -185,6 +185,10 @@ int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *batch, double *x, doub
  * (r and z may be NULL to ask for it).  Fails when the last run used the polynomial. */
 int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out);
 
+/* What this GPU streams (bench.py `box`): a read of `bytes` through a plain 16-byte-per-lane summing kernel and a device-to-device
+ * copy of them, HIP events, best of six; GB/s (the copy counts read + write). */
+int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs);
+
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */
 int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *x, double *y,

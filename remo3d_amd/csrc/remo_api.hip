@@ -939,6 +939,56 @@ int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *b, double *x, double *
     }
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_stream_read(const double2 *__restrict__ x, int64_t n2, double *__restrict__ out) {
+    double a = 0.0, b = 0.0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n2; i += int64_t(gridDim.x) * blockDim.x) {
+        const double2 v = x[i];
+        a += v.x; b += v.y;
+    }
+    a += b;
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = a;
+}
+}  // namespace
+
+int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs) {
+    if (!ctx || bytes < (1 << 20)) return REMO_ERR_ARG;
+    double *a = nullptr, *b = nullptr, *o = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int64_t n = bytes / 16 * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a), sizeof(double) * n));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b), sizeof(double) * n));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&o), sizeof(double) * 4096 * 4));
+        HIP_TRY(hipMemsetAsync(a, 0, sizeof(double) * n, ctx->stream));
+        HIP_TRY(hipMemsetAsync(b, 0, sizeof(double) * n, ctx->stream));
+        float best_r = 1e30f, best_c = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<const double2 *>(a), n / 2, o);
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(hipMemcpyAsync(b, a, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            float r = 0, c = 0;
+            (void)hipEventElapsedTime(&r, ctx->ev[0], ctx->ev[1]);
+            (void)hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]);
+            if (r < best_r) best_r = r;
+            if (c < best_c) best_c = c;
+        }
+        if (read_gbs) *read_gbs = double(n) * 8.0 / (double(best_r) * 1e6);
+        if (copy_gbs) *copy_gbs = 2.0 * double(n) * 8.0 / (double(best_c) * 1e6);
+        (void)hipFree(a); (void)hipFree(b); (void)hipFree(o);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (o) (void)hipFree(o);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
 int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out) {
     if (!ctx) return REMO_ERR_ARG;
     if (!b || !b->has_system || b->run_id != ctx->run_id || k < 1 || k > REMO_MAX_RHS) return fail(ctx, REMO_ERR_ARG, "bad argument");

@@ -793,7 +793,7 @@ int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowpt
     H.lev[L].nnz = h_nnz_a[L];
     for (int l = 0; l < L; ++l) H.lev[l].nnz_p = h_nnz_p[l];
     (void)d_nnz_a;
-    H.launches = 4 * (H.levels - 1) + 1;
+    H.launches = 4 * (H.levels - 1);   // pre, restrict, prolong, post per level; the tail kernel stands for the last restriction + dense solve
     H.kmax = kmax;
     return 0;
 }

@@ -37,7 +37,7 @@ with solver.Context(0) as ctx:
         for rep in range(2):
             for wi, (mesh, sigma, sources, evals) in enumerate(work):
                 t0 = time.time()
-                outs, st, rc = ctx.solve_batch(mesh, sigma, sources, evals, solver.make_opts(coarse=coarse, rtol=1e-10, precision=precision, maxsteps=4000))
+                outs, st, rc = ctx.solve_batch(mesh, sigma, sources, evals, solver.make_opts(coarse=coarse, rtol=float(os.environ.get("RTOL", "1e-10")), precision=precision, maxsteps=4000, check_every=int(os.environ.get("CHECK", "5"))))
                 if rc != 0:
                     print(coarse, "rc", rc, ctx.last_error() if hasattr(ctx, "last_error") else "", flush=True)
                     continue

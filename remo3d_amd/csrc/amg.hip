@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__res
                                                 double *__restrict__ cv, int32_t *flag) {   // PASS 1: crp has been clamped to the capacity of cc / cv (k_clamp_rowptr)
     __shared__ int32_t keys[4][SLOTS];
     __shared__ int32_t list[4][SLOTS];
+    __shared__ double terms[4][PASS == 1 ? SLOTS / 2 : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + wave;
     if (row >= nx) return;                      // no block-wide barriers below: a wave works on its own tables
@@ -283,17 +284,40 @@ __global__ void __launch_bounds__(256) k_spgemm(int64_t nx, const int32_t *__res
     const int64_t off = crp[row];
     const int room = int(crp[row + 1] - crp[row]);   // < c only when the product outgrew its arrays (flagged by k_clamp_rowptr): stay inside them
     if (c > room) c = room;
-    for (int t = lane; t < c; t += 64) {
-        const int32_t j = L[t];
-        double acc = 0.0;
-        for (int32_t p = xs; p < xe; ++p) {      // fixed order over the row of X
+    if (c <= 0) return;
+    // values: the (output column, entry of X) pairs are spread over the lanes, one sorted-row lookup each, a chunk of X entries at
+    // a time; the terms go through LDS and every output column adds its own in the order of X's row (not found = + 0.0):
+    // the same sums as a serial walk, without its chain of dependent lookups
+    double *V = terms[wave];
+    constexpr int NACC = SLOTS / 128;            // output columns per lane: c <= SLOTS / 2
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    const int pc = c >= 64 ? 1 : 64 / c;         // entries of X per round
+    for (int32_t p0 = xs; p0 < xe; p0 += pc) {
+        const int np = (xe - p0 < pc) ? int(xe - p0) : pc;
+        for (int idx = lane; idx < c * np; idx += 64) {
+            const int t = idx / np, pp = idx - t * np;
+            const int32_t j = L[t];
+            const int32_t p = p0 + pp;
             const int32_t k = xc[p];
             const int32_t ys = yrp[k], ye = yrp[k + 1];
             const int32_t q = lower_bound_i32(yc, ys, ye, j);
-            if (q < ye && yc[q] == j) acc += xv[p] * yv[q];
+            V[idx] = (q < ye && yc[q] == j) ? xv[p] * yv[q] : 0.0;
         }
-        cc[off + t] = j;
-        cv[off + t] = acc;
+        wave_sync();
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int t = lane + 64 * a;
+            if (t < c)
+                for (int pp = 0; pp < np; ++pp) acc[a] += V[t * np + pp];
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        const int t = lane + 64 * a;
+        if (t < c) { cc[off + t] = L[t]; cv[off + t] = acc[a]; }
     }
 }
 

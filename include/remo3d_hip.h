@@ -188,6 +188,9 @@ int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, con
 /* What this GPU streams (bench.py `box`): a read of `bytes` through a plain 16-byte-per-lane summing kernel and a device-to-device
  * copy of them, HIP events, best of six; GB/s (the copy counts read + write). */
 int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs);
+/* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
+ * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */
+int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
 
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */

@@ -950,7 +950,42 @@ __global__ void __launch_bounds__(256) k_stream_read(const double2 *__restrict__
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = a;
 }
+// a chain of dependent fp32 multiply-adds per wave, one wave per SIMD-sized slice of the chip: its rate follows the shader clock
+__global__ void __launch_bounds__(64) k_clock_probe(int iters, float *__restrict__ out) {
+    float a = float(threadIdx.x) * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a = __builtin_fmaf(a, 0.999999f, 0.5f);
+    }
+    if (a == 123.456f) out[blockIdx.x] = a;
+}
 }  // namespace
+
+int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave) {
+    if (!ctx || !gfma_per_wave) return REMO_ERR_ARG;
+    float *o = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&o), sizeof(float) * 1024));
+        const int iters = 1 << 16;   // x 16 dependent multiply-adds
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(k_clock_probe, dim3(1024), dim3(64), 0, ctx->stream, iters, o);
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+            if (ms < best) best = ms;
+        }
+        *gfma_per_wave = double(iters) * 16.0 / (double(best) * 1e6);
+        (void)hipFree(o);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (o) (void)hipFree(o);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
 
 int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs) {
     if (!ctx || bytes < (1 << 20)) return REMO_ERR_ARG;

@@ -13,7 +13,8 @@
 //   coarse matrix A' = R (A P), two more products
 //   coarsest      dense inverse (Gauss-Jordan in LDS, <= 64 rows)
 // Cycle: V(1,1) with damped Jacobi (omega = 1.6 / lmax, the one-term Chebyshev polynomial of [lmax / 4, lmax]), symmetric, so
-// the PCG sees a fixed symmetric positive definite preconditioner.
+// the PCG sees a fixed symmetric positive definite preconditioner.  The host waits ONCE per level during the setup (number of
+// aggregates); product sizes stay on the device (capacity-bound arrays, clamped row pointers, flags read at the next wait).
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
@@ -40,8 +41,6 @@ namespace {
         hipError_t e__ = (expr);                                                                           \
         if (e__ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
-
-// LDS hash slots per wave of the sparse product: 128 first (rows of at most 64 distinct columns), 512 when a row overflows
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -122,9 +121,9 @@ __global__ void __launch_bounds__(256) k_mis_max(int64_t n, const int32_t *__res
     m1[i] = m;
 }
 
-// second hop + decision; tup is updated in place (the other threads read m1 only); undecided[0] counts what is left
+// second hop + decision; tup is updated in place (the other threads read m1 only)
 __global__ void __launch_bounds__(256) k_mis_update(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                    uint64_t *__restrict__ tup, const uint64_t *__restrict__ m1, int32_t *undecided) {
+                                                    uint64_t *__restrict__ tup, const uint64_t *__restrict__ m1) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t t = tup[i];
@@ -133,7 +132,6 @@ __global__ void __launch_bounds__(256) k_mis_update(int64_t n, const int32_t *__
     for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) { const uint64_t v = m1[col[p]]; m = v > m ? v : m; }
     if (m == t) tup[i] = (uint64_t(2) << 62) | (t & kTupMask);
     else if ((m >> 62) == 2) tup[i] = t & kTupMask;
-    else atomicAdd(undecided, 1);
 }
 
 // After the fixed number of iterations a few nodes (0.6 % at 80 k rows after six) are still undecided: they have no root
@@ -657,7 +655,7 @@ void spgemm_async(Arena &ar, bool permanent, hipStream_t s, const Csr &X, const 
 
 std::atomic<int> g_product_hint[2][kAmgMaxLevels][3];   // [2D | 3D matrices][level][S P0, A P, R (A P)]; 0 / 1: 128 slots, 2: 512
 std::atomic<int> g_ap_room[2];                          // log2 of the extra room of A P beyond 4 nnz(A) (0 .. 3)
-constexpr int kFlagSlots = 64;                          // [0] setup flags, [1] scratch counter, [8 + 3 level + product] product flags
+constexpr int kFlagSlots = 64;                          // [0] setup flags, [8 + 3 level + product] product flags
 
 // one attempt: 0 = built, 1 = a product outgrew its tables or arrays (the hints have been raised: try again), -1 = failed
 int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int kmax, AmgT<double> &H,
@@ -669,7 +667,7 @@ int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowpt
     HIP_OK(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long) * (kAmgMaxLevels + 1), s));
     int32_t h_flags[kFlagSlots] = {};
     int32_t h_nnz_a[kAmgMaxLevels] = {}, h_nnz_p[kAmgMaxLevels] = {};
-    const int32_t *d_nnz_a[kAmgMaxLevels] = {}, *d_nnz_p[kAmgMaxLevels] = {};   // where the exact counts live on the device
+    const int32_t *d_nnz_p[kAmgMaxLevels] = {};   // where the exact entry counts of the prolongators live on the device
     // looks at the flags read back so far; products of the levels below `upto`
     auto check = [&](int upto) -> int {
         int again = 0;   // the products first: a cut-off product leaves rows without a diagonal behind, which is then flagged as well
@@ -746,7 +744,7 @@ int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowpt
         hipLaunchKernelGGL(k_mis_init, dim3(g), dim3(256), 0, s, n, tup);
         for (int it = 0; it < 10; ++it) {   // a fixed number of iterations, no read-back (460 of 80 k nodes are open after six, none after twelve); k_mis_finish settles stragglers
             hipLaunchKernelGGL(k_mis_max, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
-            hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1, d_flag + 1);
+            hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
         }
         hipLaunchKernelGGL(k_mis_finish, dim3(g), dim3(256), 0, s, n, A.rowptr, A.col, tup, m1);
         hipLaunchKernelGGL(k_mis_flags, dim3(g), dim3(256), 0, s, n, m1, isroot);
@@ -816,7 +814,6 @@ int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowpt
     if (verdict != 0) return verdict;
     H.lev[L].nnz = h_nnz_a[L];
     for (int l = 0; l < L; ++l) H.lev[l].nnz_p = h_nnz_p[l];
-    (void)d_nnz_a;
     H.launches = 4 * (H.levels - 1);   // pre, restrict, prolong, post per level; the tail kernel stands for the last restriction + dense solve
     H.kmax = kmax;
     return 0;

@@ -187,10 +187,11 @@ def box_stream(device):
             rc = _lib.load().remo_debug_stream(ctx._h, 1 << 30, C.byref(r), C.byref(c))
             if rc != 0:
                 return dict(error=ctx.last_error())
-            g = C.c_double(0)
+            g, m, mc = C.c_double(0), C.c_double(0), C.c_double(0)
             _lib.load().remo_debug_clock(ctx._h, C.byref(g))
-            return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, dependent_fma_G_per_s_per_wave=g.value,
-                        note="1 GiB, 16-byte loads in a summing kernel / hipMemcpy device to device (read + write), best of 6; chain of dependent fp32 "
+            _lib.load().remo_debug_stream(ctx._h, 128 << 20, C.byref(m), C.byref(mc))   # fits the Infinity Cache: re-read back to back
+            return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, infinity_cache_reread_GBs=m.value, dependent_fma_G_per_s_per_wave=g.value,
+                        note="1 GiB, 16-byte loads in a summing kernel / hipMemcpy device to device (read + write), best of 6; 128 MiB re-read four times back to back (Infinity Cache); chain of dependent fp32 "
                              "multiply-adds per wave, 1024 waves at once (follows the shader clock under load)")
     except Exception as ex:   # the probe is context, never a reason to lose the line
         return dict(error="%s: %s" % (type(ex).__name__, ex))

@@ -186,7 +186,8 @@ int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *batch, double *x, doub
 int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out);
 
 /* What this GPU streams (bench.py `box`): a read of `bytes` through a plain 16-byte-per-lane summing kernel and a device-to-device
- * copy of them, HIP events, best of six; GB/s (the copy counts read + write). */
+ * copy of them, HIP events, best of six; GB/s (the copy counts read + write).  With bytes <= 192 MiB the read figure is that of four
+ * back-to-back re-reads of the buffer, i.e. of the 256 MB Infinity Cache rather than of HBM. */
 int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs);
 /* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
  * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */

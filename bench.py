@@ -190,7 +190,10 @@ def box_stream(device):
             g, m, mc = C.c_double(0), C.c_double(0), C.c_double(0)
             _lib.load().remo_debug_clock(ctx._h, C.byref(g))
             _lib.load().remo_debug_stream(ctx._h, 128 << 20, C.byref(m), C.byref(mc))   # fits the Infinity Cache: re-read back to back
+            dev = (C.c_int64 * 8)()
+            _lib.load().remo_debug_device(ctx._h, dev)
             return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, infinity_cache_reread_GBs=m.value, dependent_fma_G_per_s_per_wave=g.value,
+                        device=dict(compute_units=dev[0], clock_MHz=dev[1] / 1e3, memory_clock_MHz=dev[2] / 1e3, bus_bits=dev[3], l2_bytes=dev[4], memory_MiB=dev[5]),
                         note="1 GiB, 16-byte loads in a summing kernel / hipMemcpy device to device (read + write), best of 6; 128 MiB re-read four times back to back (Infinity Cache); chain of dependent fp32 "
                              "multiply-adds per wave, 1024 waves at once (follows the shader clock under load)")
     except Exception as ex:   # the probe is context, never a reason to lose the line

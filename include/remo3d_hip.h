@@ -192,6 +192,8 @@ int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *
 /* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
  * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */
 int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
+/* hipDeviceProp_t of the context's GPU: compute units, clock kHz, memory clock kHz, bus width, L2 bytes, memory MiB, LDS bytes per CU, revision. */
+int remo_debug_device(remo_ctx_t *ctx, int64_t *out8);
 
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */

@@ -987,6 +987,21 @@ int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave) {
     }
 }
 
+int remo_debug_device(remo_ctx_t *ctx, int64_t *out8) {
+    if (!ctx || !out8) return REMO_ERR_ARG;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, ctx->device) != hipSuccess) return fail(ctx, REMO_ERR_DEVICE, "hipGetDeviceProperties failed");
+    out8[0] = pr.multiProcessorCount;
+    out8[1] = pr.clockRate;          // kHz
+    out8[2] = pr.memoryClockRate;    // kHz
+    out8[3] = pr.memoryBusWidth;
+    out8[4] = pr.l2CacheSize;
+    out8[5] = int64_t(pr.totalGlobalMem >> 20);
+    out8[6] = pr.maxSharedMemoryPerMultiProcessor;
+    out8[7] = pr.asicRevision;
+    return REMO_OK;
+}
+
 int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs) {
     if (!ctx || bytes < (1 << 20)) return REMO_ERR_ARG;
     double *a = nullptr, *b = nullptr, *o = nullptr;

@@ -194,6 +194,8 @@ int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *
 int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
 /* hipDeviceProp_t of the context's GPU: compute units, clock kHz, memory clock kHz, bus width, L2 bytes, memory MiB, LDS bytes per CU, revision. */
 int remo_debug_device(remo_ctx_t *ctx, int64_t *out8);
+/* XCD (hardware register XCC_ID) of workgroups 0 .. nblocks-1 of a probe launch: the SpMM's row schedule assumes b mod 8. */
+int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
 
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */

@@ -987,6 +987,32 @@ int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave) {
     }
 }
 
+namespace {
+// which XCD (accelerator die) a workgroup runs on: hardware register XCC_ID (id 20, 4 bits) - the SpMM's row schedule assumes
+// workgroup b runs on XCD b mod 8
+__global__ void __launch_bounds__(64) k_xcc_probe(int32_t *__restrict__ out) {
+    const int32_t id = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    if (threadIdx.x == 0) out[blockIdx.x] = id;
+}
+}  // namespace
+
+int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks) {
+    if (!ctx || !out || nblocks < 1 || nblocks > 65536) return REMO_ERR_ARG;
+    int32_t *d = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(int32_t) * nblocks));
+        hipLaunchKernelGGL(k_xcc_probe, dim3(nblocks), dim3(64), 0, ctx->stream, d);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(out, d, sizeof(int32_t) * nblocks, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (d) (void)hipFree(d);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
 int remo_debug_device(remo_ctx_t *ctx, int64_t *out8) {
     if (!ctx || !out8) return REMO_ERR_ARG;
     hipDeviceProp_t pr;

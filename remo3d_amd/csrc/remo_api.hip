@@ -950,6 +950,19 @@ __global__ void __launch_bounds__(256) k_stream_read(const double2 *__restrict__
     for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = a;
 }
+// scattered 16-byte reads from a 2 MiB buffer (resident in every XCD's 4 MiB L2 after the first touch): the L2 -> L1 -> lane path
+// the SpMM's x gather lives on
+__global__ void __launch_bounds__(256) k_l2_gather(const double2 *__restrict__ x, uint32_t mask, int iters, double *__restrict__ out) {
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    double a = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        const double2 v = x[idx & mask];
+        a += v.x + v.y;
+        idx = idx * 1664525u + 1013904223u;
+    }
+    if (a == 1.2345e300) out[0] = a;
+}
+
 // a chain of dependent fp32 multiply-adds per wave, one wave per SIMD-sized slice of the chip: its rate follows the shader clock
 __global__ void __launch_bounds__(64) k_clock_probe(int iters, float *__restrict__ out) {
     float a = float(threadIdx.x) * 1e-3f;
@@ -960,6 +973,36 @@ __global__ void __launch_bounds__(64) k_clock_probe(int iters, float *__restrict
     if (a == 123.456f) out[blockIdx.x] = a;
 }
 }  // namespace
+
+int remo_debug_l2_gather(remo_ctx_t *ctx, double *gbs) {
+    if (!ctx || !gbs) return REMO_ERR_ARG;
+    double *a = nullptr, *o = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int64_t n2 = (int64_t(2) << 20) / 16;   // 2 MiB of 16-byte elements (a power of two)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a), size_t(n2) * 16));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&o), 64));
+        HIP_TRY(hipMemsetAsync(a, 0, size_t(n2) * 16, ctx->stream));
+        const int blocks = 4096, iters = 64;
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(k_l2_gather, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const double2 *>(a), uint32_t(n2 - 1), iters, o);
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+            if (ms < best) best = ms;
+        }
+        *gbs = double(blocks) * 256.0 * iters * 16.0 / (double(best) * 1e6);
+        (void)hipFree(a); (void)hipFree(o);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        if (a) (void)hipFree(a);
+        if (o) (void)hipFree(o);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
 
 int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave) {
     if (!ctx || !gfma_per_wave) return REMO_ERR_ARG;

@@ -193,7 +193,7 @@ def box_stream(device):
             dev = (C.c_int64 * 8)()
             _lib.load().remo_debug_device(ctx._h, dev)
             lg = C.c_double(0)
-            _lib.load().remo_debug_l2_gather(ctx._h, C.byref(lg))
+            _lib.load().remo_debug_cache_gather(ctx._h, C.byref(lg))
             xcc = (C.c_int32 * 1024)()
             _lib.load().remo_debug_xcc(ctx._h, xcc, 1024)
             xl = [int(v) for v in xcc]

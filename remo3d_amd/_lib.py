@@ -48,7 +48,7 @@ class RemoStats(C.Structure):
 
 EXPORTS = ["remo_abi_version", "remo_opts_default", "remo_ctx_create", "remo_ctx_destroy", "remo_last_error",
            "remo_solve_batch", "remo_batch_create", "remo_batch_run", "remo_batch_fetch", "remo_batch_destroy",
-           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_apply_coarse", "remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_l2_gather", "remo_debug_xcc", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic", "remo_debug_tune"]
+           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_apply_coarse", "remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_cache_gather", "remo_debug_xcc", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic", "remo_debug_tune"]
 
 _lib = None
 
@@ -91,8 +91,8 @@ def load():
     L.remo_batch_apply_coarse.argtypes = [vp, vp, C.c_int32, dp, dp, C.c_int32, i64p]
     L.remo_debug_xcc.restype = C.c_int
     L.remo_debug_xcc.argtypes = [vp, ip, C.c_int32]
-    L.remo_debug_l2_gather.restype = C.c_int
-    L.remo_debug_l2_gather.argtypes = [vp, dp]
+    L.remo_debug_cache_gather.restype = C.c_int
+    L.remo_debug_cache_gather.argtypes = [vp, dp]
     L.remo_debug_device.restype = C.c_int
     L.remo_debug_device.argtypes = [vp, i64p]
     L.remo_debug_clock.restype = C.c_int

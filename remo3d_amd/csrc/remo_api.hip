@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(64) k_clock_probe(int iters, float *__restrict
 }
 }  // namespace
 
-int remo_debug_l2_gather(remo_ctx_t *ctx, double *gbs) {
+int remo_debug_cache_gather(remo_ctx_t *ctx, double *gbs) {
     if (!ctx || !gbs) return REMO_ERR_ARG;
     double *a = nullptr, *o = nullptr;
     try {

@@ -192,13 +192,14 @@ def box_stream(device):
             _lib.load().remo_debug_stream(ctx._h, 128 << 20, C.byref(m), C.byref(mc))   # fits the Infinity Cache: re-read back to back
             dev = (C.c_int64 * 8)()
             _lib.load().remo_debug_device(ctx._h, dev)
-            lg = C.c_double(0)
-            _lib.load().remo_debug_cache_gather(ctx._h, C.byref(lg))
+            lg, fg = C.c_double(0), C.c_double(0)
+            _lib.load().remo_debug_cache_gather(ctx._h, 2 << 20, C.byref(lg))
+            _lib.load().remo_debug_cache_gather(ctx._h, 256 << 20, C.byref(fg))
             xcc = (C.c_int32 * 1024)()
             _lib.load().remo_debug_xcc(ctx._h, xcc, 1024)
             xl = [int(v) for v in xcc]
             round_robin = all(xl[b] == (xl[0] + b) % 8 for b in range(1024))
-            return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, infinity_cache_reread_GBs=m.value, l2_scattered_16B_reads_GBs=lg.value, dependent_fma_G_per_s_per_wave=g.value,
+            return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, infinity_cache_reread_GBs=m.value, l2_scattered_16B_reads_GBs=lg.value, scattered_16B_reads_over_256MiB_GBs=fg.value, dependent_fma_G_per_s_per_wave=g.value,
                         xcd_of_workgroups_0_to_15=xl[:16], xcd_is_workgroup_mod_8=bool(round_robin),
                         xcd_histogram=[xl.count(v) for v in range(8)],
                         device=dict(compute_units=dev[0], clock_MHz=dev[1] / 1e3, memory_clock_MHz=dev[2] / 1e3, bus_bits=dev[3], l2_bytes=dev[4], memory_MiB=dev[5]),

@@ -192,8 +192,9 @@ int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *
 /* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
  * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */
 int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
-/* Scattered 16-byte reads from a 2 MiB (L2-resident) buffer by 4096 workgroups, useful GB/s: the path of the SpMM's x gather. */
-int remo_debug_cache_gather(remo_ctx_t *ctx, double *gbs);
+/* Scattered 16-byte reads from a buffer of `bytes` (a power of two) by 4096 workgroups, useful GB/s: 2 MiB stays in every XCD's L2 (the
+ * path of the SpMM's x gather); 256 MiB adds the address translation of pages scattered over the memory. */
+int remo_debug_cache_gather(remo_ctx_t *ctx, int64_t bytes, double *gbs);
 /* hipDeviceProp_t of the context's GPU: compute units, clock kHz, memory clock kHz, bus width, L2 bytes, memory MiB, LDS bytes per CU, revision. */
 int remo_debug_device(remo_ctx_t *ctx, int64_t *out8);
 /* XCD (hardware register XCC_ID) of workgroups 0 .. nblocks-1 of a probe launch: the SpMM's row schedule assumes b mod 8. */

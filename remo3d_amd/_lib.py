@@ -92,7 +92,7 @@ def load():
     L.remo_debug_xcc.restype = C.c_int
     L.remo_debug_xcc.argtypes = [vp, ip, C.c_int32]
     L.remo_debug_cache_gather.restype = C.c_int
-    L.remo_debug_cache_gather.argtypes = [vp, dp]
+    L.remo_debug_cache_gather.argtypes = [vp, C.c_int64, dp]
     L.remo_debug_device.restype = C.c_int
     L.remo_debug_device.argtypes = [vp, i64p]
     L.remo_debug_clock.restype = C.c_int

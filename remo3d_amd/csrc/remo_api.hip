@@ -974,12 +974,12 @@ __global__ void __launch_bounds__(64) k_clock_probe(int iters, float *__restrict
 }
 }  // namespace
 
-int remo_debug_cache_gather(remo_ctx_t *ctx, double *gbs) {
-    if (!ctx || !gbs) return REMO_ERR_ARG;
+int remo_debug_cache_gather(remo_ctx_t *ctx, int64_t bytes, double *gbs) {
+    if (!ctx || !gbs || bytes < (1 << 20) || bytes > (int64_t(1) << 32) || (bytes & (bytes - 1)) != 0) return REMO_ERR_ARG;   // a power of two
     double *a = nullptr, *o = nullptr;
     try {
         HIP_TRY(hipSetDevice(ctx->device));
-        const int64_t n2 = (int64_t(2) << 20) / 16;   // 2 MiB of 16-byte elements (a power of two)
+        const int64_t n2 = bytes / 16;   // 16-byte elements
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a), size_t(n2) * 16));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&o), 64));
         HIP_TRY(hipMemsetAsync(a, 0, size_t(n2) * 16, ctx->stream));

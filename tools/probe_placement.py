@@ -31,5 +31,5 @@ for pad_mb in [0, 64, 200, 512, 1000, 1536, 3000, 7000]:
         for rep in range(3):
             y, ms = b.spmv(x, reps=50)
             res.append(1e3 * ms)
-        print("dummy allocations so far %5d MB (+%d): SpMM %s us" % (sum([0, 64, 200, 512, 1000, 1536, 3000, 7000][:len(pads) + (0 if pad_mb else 1)]) if False else pad_mb, len(pads), " ".join("%.1f" % v for v in res)), flush=True)
+        print("after a further dummy allocation of %5d MB (%d held): SpMM %s us" % (pad_mb, len(pads), " ".join("%.1f" % v for v in res)), flush=True)
         b.close()

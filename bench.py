@@ -202,7 +202,7 @@ def box_stream(device):
             return dict(stream_read_GBs=r.value, stream_copy_GBs=c.value, infinity_cache_reread_GBs=m.value, l2_scattered_16B_reads_GBs=lg.value, scattered_16B_reads_over_256MiB_GBs=fg.value, dependent_fma_G_per_s_per_wave=g.value,
                         xcd_of_workgroups_0_to_15=xl[:16], xcd_is_workgroup_mod_8=bool(round_robin),
                         xcd_histogram=[xl.count(v) for v in range(8)],
-                        device=dict(compute_units=dev[0], clock_MHz=dev[1] / 1e3, memory_clock_MHz=dev[2] / 1e3, bus_bits=dev[3], l2_bytes=dev[4], memory_MiB=dev[5]),
+                        device=dict(compute_units=dev[0], clock_MHz=dev[1] / 1e3, memory_clock_MHz=dev[2] / 1e3, bus_bits=dev[3], l2_bytes=dev[4], memory_MiB=dev[5], lds_bytes_per_cu=dev[6], revision=dev[7]),
                         note="1 GiB, 16-byte loads in a summing kernel / hipMemcpy device to device (read + write), best of 6; 128 MiB re-read four times back to back (Infinity Cache); chain of dependent fp32 "
                              "multiply-adds per wave, 1024 waves at once (follows the shader clock under load)")
     except Exception as ex:   # the probe is context, never a reason to lose the line

@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip.h lists the keys)")
+                    help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip_debug.h lists the keys)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket every k-th SpMV launch of a solve with HIP events (a bracket costs the stream ~1.5 us: bracketing "

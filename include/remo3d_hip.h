@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 4
+#define REMO_ABI_VERSION 5
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -185,21 +185,6 @@ int remo_batch_get_vectors(remo_ctx_t *ctx, remo_batch_t *batch, double *x, doub
  * (r and z may be NULL to ask for it).  Fails when the last run used the polynomial. */
 int remo_batch_apply_coarse(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *r, double *z, int32_t fp32, int64_t *nv_out);
 
-/* What this GPU streams (bench.py `box`): a read of `bytes` through a plain 16-byte-per-lane summing kernel and a device-to-device
- * copy of them, HIP events, best of six; GB/s (the copy counts read + write).  With bytes <= 192 MiB the read figure is that of four
- * back-to-back re-reads of the buffer, i.e. of the 256 MB Infinity Cache rather than of HBM. */
-int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs);
-/* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
- * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */
-int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
-/* Scattered 16-byte reads from a buffer of `bytes` (a power of two) by 4096 workgroups, useful GB/s: 2 MiB stays in every XCD's L2 (the
- * path of the SpMM's x gather); 256 MiB adds the address translation of pages scattered over the memory. */
-int remo_debug_cache_gather(remo_ctx_t *ctx, int64_t bytes, double *gbs);
-/* hipDeviceProp_t of the context's GPU: compute units, clock kHz, memory clock kHz, bus width, L2 bytes, memory MiB, LDS bytes per CU, revision. */
-int remo_debug_device(remo_ctx_t *ctx, int64_t *out8);
-/* XCD (hardware register XCC_ID) of workgroups 0 .. nblocks-1 of a probe launch: the SpMM's row schedule assumes b mod 8. */
-int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
-
 /* y = A x on the device with the batch's matrix, k interleaved columns (x[n_free*k] row-major);
  * reps >= 1 launches are timed with HIP events, average ms returned in *ms_avg. */
 int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const double *x, double *y,
@@ -219,15 +204,6 @@ double remo_host_factor_error(void);
 int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes /*[6]: n_dof,n_free,nnz,n_edges,n_faces,nld*/,
                        int32_t *rowptr /*[n_free+1] or NULL*/, int32_t *col /*[nnz] or NULL*/,
                        int32_t *freeid /*[n_dof] or NULL*/);
-
-/* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
- * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
- * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;
- * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
- * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
- * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage).  Process-global. */
-void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,43 @@
+/*
+ * remo3d_hip_debug.h — probes and tuning knobs of libremo3d_hip.so for tests/, tools/ and bench.py's `box` record.
+ * NOT part of the drop-in boundary (include/remo3d_hip.h is: the surface SURVEY.md section 8b describes, replacing the seam
+ * of remo3d/workers/worker.py:32-35, 110); nothing here is needed to run a batch, and the knobs are process-global.
+ */
+#ifndef REMO3D_HIP_DEBUG_H
+#define REMO3D_HIP_DEBUG_H
+
+#include "remo3d_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* What this GPU streams (bench.py `box`): a read of `bytes` through a plain 16-byte-per-lane summing kernel and a device-to-device
+ * copy of them, HIP events, best of six; GB/s (the copy counts read + write).  With bytes <= 192 MiB the read figure is that of four
+ * back-to-back re-reads of the buffer, i.e. of the 256 MB Infinity Cache rather than of HBM. */
+int remo_debug_stream(remo_ctx_t *ctx, int64_t bytes, double *read_gbs, double *copy_gbs);
+/* Rate of a chain of DEPENDENT fp32 multiply-adds of one wave (1024 waves over the chip at once), in 1e9 per second: follows the
+ * shader clock under load - the part of the box-to-box spread that the stream figures do not show. */
+int remo_debug_clock(remo_ctx_t *ctx, double *gfma_per_wave);
+/* Scattered 16-byte reads from a buffer of `bytes` (a power of two) by 4096 workgroups, useful GB/s: 2 MiB stays in every XCD's L2 (the
+ * path of the SpMM's x gather); 256 MiB adds the address translation of pages scattered over the memory. */
+int remo_debug_cache_gather(remo_ctx_t *ctx, int64_t bytes, double *gbs);
+/* hipDeviceProp_t of the context's GPU: compute units, clock kHz, memory clock kHz, bus width, L2 bytes, memory MiB, LDS bytes per CU, revision. */
+int remo_debug_device(remo_ctx_t *ctx, int64_t *out8);
+/* XCD (hardware register XCC_ID) of workgroups 0 .. nblocks-1 of a probe launch: the SpMM's row schedule assumes b mod 8. */
+int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
+
+
+/* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
+ * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
+ * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;
+ * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
+ * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
+ * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
+ * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage).  Process-global. */
+void remo_debug_tune(int32_t key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMO3D_HIP_DEBUG_H */

@@ -46,9 +46,13 @@ class RemoStats(C.Structure):
         return d
 
 
+# include/remo3d_hip.h: the drop-in boundary + inspection hooks of the parity tests
 EXPORTS = ["remo_abi_version", "remo_opts_default", "remo_ctx_create", "remo_ctx_destroy", "remo_last_error",
            "remo_solve_batch", "remo_batch_create", "remo_batch_run", "remo_batch_fetch", "remo_batch_destroy",
-           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_apply_coarse", "remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_cache_gather", "remo_debug_xcc", "remo_batch_spmv", "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic", "remo_debug_tune"]
+           "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_apply_coarse", "remo_batch_spmv",
+           "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic"]
+# include/remo3d_hip_debug.h: probes and tuning knobs (tests, tools, bench.py's `box` record) - not part of the boundary
+DEBUG_EXPORTS = ["remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_cache_gather", "remo_debug_xcc", "remo_debug_tune"]
 
 _lib = None
 

@@ -838,9 +838,11 @@ bool amg_setup(Arena &ar, hipStream_t s, int dim, int64_t nv, const int32_t *row
         }
         if (why.empty()) why = "the products did not fit after several attempts";
         H = AmgT<double>{};
+        ar.lo_off = lo0;                   // the fallback (polynomial) sees the arena as it was before the hierarchy was attempted
         return false;
     } catch (const std::exception &ex) {
         ar.hi_release(hi0);
+        ar.lo_off = lo0;
         H = AmgT<double>{};
         why = ex.what();
         return false;

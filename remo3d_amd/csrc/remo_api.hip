@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/remo3d_hip.h"
+#include "../../include/remo3d_hip_debug.h"
 #include "fem_p3.h"
 #include "kernels.h"
 #include "amg.h"

@@ -351,7 +351,7 @@ class Model:
         free_ctx = queue.Queue()
         for c in ctxs:
             free_ctx.put(c)
-        acc = dict(mesh=0.0, solve=0.0, points=0, failed_batches=0, not_converged=0, first_error=None, pcg_steps=0)
+        acc = dict(mesh=0.0, solve=0.0, points=0, failed_batches=0, not_converged=0, first_error=None, pcg_steps=0, programming_error=None)
         lock = threading.Lock()
         # batches drawn ahead of the solver so that their meshes are in the making: the whole share at once when it is
         # fixed anyway, a few (they are OWNED once drawn) under the pull schedule
@@ -361,7 +361,10 @@ class Model:
 
         def next_batch():
             with draw_lock:
-                while len(ahead) < depth:
+                # under the pull schedule a drawn batch is OWNED: near the end of the sweep a rank must not sit on a queue of
+                # batches the other ranks are idle for - draw ahead no further than its fair part of what is left
+                cap = depth if schedule == "static" else max(1, min(depth, 1 + bq.remaining_hint() // (2 * max(1, sweep.world_size()))))
+                while len(ahead) < cap:
                     try:
                         bi = next(draw)
                     except StopIteration:
@@ -414,15 +417,18 @@ class Model:
                 with lock:
                     acc["mesh"] += t1 - t0; acc["solve"] += t2 - t1; acc["points"] += n
                     acc["not_converged"] += int(rc == solver.REMO_NOT_CONVERGED); acc["pcg_steps"] += int(st.get("pcg_steps", 0))
-            except (TypeError, AttributeError, NameError):
-                raise                    # programming errors (e.g. in a custom mesh_provider) are not batch failures
             except Exception as ex:
-                for di, ti in rows:      # any failure in a batch -> NaN for its records (worker.py:135-138)
+                for di, ti in rows:      # any failure in a batch -> NaN for its records (worker.py:135-138: a bare except)
                     results[di, ti] = np.nan
                 with lock:               # ... but not silently: the reference's worker at least shows it on stderr
                     acc["failed_batches"] += 1
                     if acc["first_error"] is None:
                         acc["first_error"] = "batch {}: {}: {}".format(bi, type(ex).__name__, ex)
+                    # a programming error (e.g. in a custom mesh_provider) is recorded like any other failure HERE - a rank that
+                    # raised now would miss the collectives below and leave the other ranks waiting in the all-reduce - and is
+                    # raised once they are through
+                    if isinstance(ex, (TypeError, AttributeError, NameError)) and acc["programming_error"] is None:
+                        acc["programming_error"] = ex
 
         def drive():
             while True:
@@ -432,24 +438,29 @@ class Model:
                 run_batch(bi)
 
         t_busy = time.time()
-        if len(ctxs) > 1 and share_len > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=len(ctxs)) as tp:     # one host thread per context; ctypes calls release the GIL
-                for fut in [tp.submit(drive) for _ in ctxs]:
-                    fut.result()
-        else:
-            drive()
+        try:
+            if len(ctxs) > 1 and share_len > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=len(ctxs)) as tp:     # one host thread per context; ctypes calls release the GIL
+                    for fut in [tp.submit(drive) for _ in ctxs]:
+                        fut.result()
+            else:
+                drive()
+        finally:
+            if pool is not None:     # whatever happened above, the mesh processes do not outlive the sweep
+                pool.shutdown(wait=False, cancel_futures=True)
         t_busy = time.time() - t_busy
         mine = list(bq.taken)
         t_mesh, t_solve, n_points = acc["mesh"], acc["solve"], acc["points"]
-        if pool is not None:
-            pool.shutdown(wait=False, cancel_futures=True)
+        bq.check_complete()          # collective: every batch was taken exactly once over the ranks
         results = sweep.combine(results)
         self.logs = {name: np.vstack([measurement_depths, results[:, i]]).T for i, name in enumerate(self.tools.keys())}
         self.timing = dict(total_s=time.time() - start, mesh_s=t_mesh, solve_s=t_solve, points=n_points, batches=len(batches),
                            my_batches=len(mine), world_size=sweep.world_size(), schedule=schedule, busy_s=t_busy,
                            busy_s_per_rank=[b[0] for b in sweep.gather_floats([t_busy])], failed_batches=acc["failed_batches"],
                            not_converged=acc["not_converged"], first_error=acc["first_error"], pcg_steps=acc["pcg_steps"])
+        if acc["programming_error"] is not None:     # every rank is through the collectives: now it may raise
+            raise acc["programming_error"]
         if verbose and acc["failed_batches"]:
             print("rank {}: {} of {} batches failed (NaN in the logs); first: {}".format(sweep.rank(), acc["failed_batches"], len(mine), acc["first_error"]))
         if verbose and acc["not_converged"]:

@@ -42,7 +42,35 @@ def my_share(n_batches: int, r: Optional[int] = None, w: Optional[int] = None) -
     return range(r, n_batches, w)
 
 
-_QUEUE_SEQ = 0
+_STORE = None          # the TCPStore the sweep owns (dynamic schedule); created once per process group, collectively
+_SWEEP_SEQ = 0         # rank 0's count of dynamic queues: the id it broadcasts names the shared counter
+
+
+def _own_store():
+    """A TCPStore of the sweep's own for the shared batch counter: rank 0 hosts it on a free local port and tells the
+    others through one broadcast (collective: every rank of the group must get here).  The process group's private
+    rendezvous store is not touched."""
+    global _STORE
+    if _STORE is not None:
+        return _STORE
+    import datetime
+    import socket
+    import torch.distributed as dist
+    host = os.environ.get("REMO_STORE_ADDR", os.environ.get("MASTER_ADDR", "127.0.0.1"))
+    box = [None]
+    if dist.get_rank() == 0:
+        s = socket.socket()
+        s.bind(("", 0))
+        port = s.getsockname()[1]
+        s.close()
+        _STORE = dist.TCPStore(host, port, world_size=dist.get_world_size(), is_master=True, wait_for_workers=False,
+                               timeout=datetime.timedelta(seconds=300))
+        box[0] = port
+    dist.broadcast_object_list(box, src=0)
+    if dist.get_rank() != 0:
+        _STORE = dist.TCPStore(host, int(box[0]), world_size=dist.get_world_size(), is_master=False,
+                               timeout=datetime.timedelta(seconds=300))
+    return _STORE
 
 
 class BatchQueue:
@@ -50,25 +78,38 @@ class BatchQueue:
 
     schedule "static": the block-cyclic share (my_share).  schedule "dynamic": the reference's pull scheduling
     (remo3d.py:843-860: a worker asks the master for the next task index whenever it is free) - here every free rank
-    draws the next index from ONE shared counter, an atomic fetch-add on the process group's rendezvous store (the
-    TCPStore torchrun already runs on the node: a pull is one local round trip, ~0.1 ms against ~20 ms of a 3D batch).
-    Without a process group both schedules are range(n).  Every rank must construct its queues in the same order (the
-    counter's key is a per-process sequence number)."""
+    draws the next index from ONE shared counter, an atomic fetch-add on a TCPStore the sweep owns (rank 0 hosts it: a
+    pull is one local round trip, ~0.1 ms against ~20 ms of a 3D batch).  Without a process group both schedules are
+    range(n).  Constructing a dynamic queue is COLLECTIVE: rank 0 broadcasts the id that names the counter, so all ranks
+    draw from the same one by construction (a rank that builds a queue the others do not build blocks in the broadcast
+    instead of silently computing every batch itself); `check_complete()` after the sweep confirms through a collective
+    that the ranks together took every batch exactly once."""
 
     def __init__(self, n_batches: int, schedule: str = "static"):
-        global _QUEUE_SEQ
+        global _SWEEP_SEQ
         if schedule not in ("static", "dynamic"):
             raise ValueError("schedule must be 'static' or 'dynamic'")
         self.n = int(n_batches)
         self.schedule = schedule
         self.taken = []
-        _QUEUE_SEQ += 1
-        self._key = "remo3d_batch_queue_%d" % _QUEUE_SEQ
+        self.last_drawn = -1
+        self._key = None
         self._store = None
         d = _dist()
         if schedule == "dynamic" and d is not None and d.get_world_size() > 1:
-            from torch.distributed import distributed_c10d
-            self._store = distributed_c10d._get_default_store()
+            self._store = _own_store()
+            box = [None]
+            if d.get_rank() == 0:
+                _SWEEP_SEQ += 1
+                box[0] = "remo3d_batch_queue_%d_%d" % (os.getpid(), _SWEEP_SEQ)
+            d.broadcast_object_list(box, src=0)
+            self._key = box[0]
+
+    def remaining_hint(self) -> int:
+        """Batches not yet handed out (as of this rank's last draw; exact for the static share)."""
+        if self._store is None:
+            return max(0, len(range(rank(), self.n, world_size())) - len(self.taken))
+        return max(0, self.n - 1 - self.last_drawn)
 
     def __iter__(self):
         if self._store is None:
@@ -78,10 +119,29 @@ class BatchQueue:
             return
         while True:
             i = int(self._store.add(self._key, 1)) - 1      # fetch-add: every index is handed out exactly once
+            self.last_drawn = i
             if i >= self.n:
                 return
             self.taken.append(i)
             yield i
+
+    def check_complete(self) -> int:
+        """Collective: the ranks together took n batches (a rank that drew nothing takes part with 0).  Returns the total;
+        raises if batches were lost or taken twice (diverged counters would otherwise SUM into multiplied logs)."""
+        d = _dist()
+        mine = len(self.taken)
+        if d is None or d.get_world_size() == 1:
+            total = mine
+        else:
+            import torch
+            t = torch.tensor([float(mine)], dtype=torch.float64)
+            if d.get_backend() == "nccl":
+                t = t.cuda()
+            d.all_reduce(t, op=d.ReduceOp.SUM)
+            total = int(round(float(t.item())))
+        if total != self.n:
+            raise RuntimeError("batch queue: the ranks took %d batches in all, the sweep has %d" % (total, self.n))
+        return total
 
 
 def gather_floats(x) -> list:

@@ -39,6 +39,7 @@ class FakeContext:
 def main():
     out_path = sys.argv[1]
     schedule = sys.argv[2] if len(sys.argv) > 2 else "static"
+    mode = sys.argv[3] if len(sys.argv) > 3 else "normal"
     # no explicit sweep.init_from_env(): Model.initialize_workers joins the process group (REMO_DIST_BACKEND=gloo in the env)
     tools = ["A0.4M6.0N", "A2.0M0.5N", "N0.5M2.0A"]
     m = Model(tools)
@@ -46,10 +47,12 @@ def main():
     bore = np.array([[0.0, 0.2, 7.0], [60.0, 0.2, 7.0]])
     m.set_model_parameters(form, bore)
     m.initialize_workers(cpu_workers=1, gpu_workers=0, context_factory=lambda device: FakeContext())
-    depths = np.arange(10.0, 20.0, 0.25)
-    fail_index = 3
+    depths = np.arange(10.0, 20.0, 0.25) if mode != "one_batch" else np.array([12.0])
+    fail_index = 3 if mode != "one_batch" else -1
 
     def provider(dim, R, batch, fg, bh, dip):
+        if mode == "type_error" and batch.index == fail_index:
+            return len(None)            # a programming error inside one batch
         return "fail" if batch.index == fail_index else "ok"
 
     if schedule == "dynamic" and sweep.rank() == 0:      # a slow rank: under the pull schedule the other one takes more batches
@@ -60,10 +63,14 @@ def main():
             time.sleep(0.05)
             return slow(*a)
         m.ctx.solve_batch = slow_solve
-    m.simulate_logs(depths, domain_radius=50, batch_size=4, mesh_provider=provider, verbose=False, schedule=schedule)
+    raised = None
+    try:
+        m.simulate_logs(depths, domain_radius=50, batch_size=4 if mode != "one_batch" else 40, mesh_provider=provider, verbose=False, schedule=schedule)
+    except TypeError as ex:          # raised only after the collectives of the sweep (logs and timing are complete)
+        raised = type(ex).__name__
     n_batches = m.timing["batches"]
     mine = list(sweep.my_share(n_batches)) if schedule == "static" else None
-    res = dict(rank=sweep.rank(), world=sweep.world_size(), share=mine, calls=m.ctx.calls, n_batches=n_batches,
+    res = dict(raised=raised, rank=sweep.rank(), world=sweep.world_size(), share=mine, calls=m.ctx.calls, n_batches=n_batches,
                taken=m.timing["my_batches"], timing={k: v for k, v in m.timing.items() if k != "first_error"}, first_error=m.timing["first_error"],
                logs={k: v.tolist() for k, v in m.logs.items()})
     with open(f"{out_path}.{sweep.rank()}", "w") as f:

@@ -10,17 +10,26 @@ import pytest
 from conftest import ROOT, SIGMA3
 
 
-def test_library_exports_every_declared_symbol():
-    from remo3d_amd import _lib
-    header = open(os.path.join(ROOT, "include", "remo3d_hip.h")).read()
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(remo_[a-z_]+)\s*\(", header))
-    assert declared, "no declarations parsed"
+    return set(re.findall(r"\b(remo_[a-z_]+)\s*\(", header))
+
+
+def test_library_exports_every_declared_symbol():
+    """The public header holds the boundary + the inspection hooks and NO debug probes; those live in their own
+    header.  The library exports everything either header declares."""
+    from remo3d_amd import _lib
+    declared, debug = _declared("remo3d_hip.h"), _declared("remo3d_hip_debug.h")
+    assert declared and debug, "no declarations parsed"
+    assert not any(n.startswith("remo_debug") for n in declared), "debug probes belong in include/remo3d_hip_debug.h"
+    assert all(n.startswith("remo_debug") for n in debug)
     L = _lib.load()
-    for name in declared:
-        assert hasattr(L, name), f"{name} declared in include/remo3d_hip.h but not exported"
+    for name in declared | debug:
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert L.remo_abi_version() == 4
+    assert set(_lib.DEBUG_EXPORTS) == debug
+    assert L.remo_abi_version() == 5
 
 
 def test_options_defaults_follow_reference():

@@ -28,10 +28,10 @@ def test_share_is_block_cyclic_and_complete():
             assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
 
 
-def _run_two_ranks(tmp_path, schedule):
+def _run_two_ranks(tmp_path, schedule, mode="normal"):
     out = str(tmp_path / "res")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sweep_worker.py"), out, schedule]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sweep_worker.py"), out, schedule, mode]
     env = dict(os.environ, OMP_NUM_THREADS="1", REMO_DIST_BACKEND="gloo")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -81,15 +81,28 @@ def test_two_rank_sweep_combines_logs(tmp_path):
     assert len(res[0]["timing"]["busy_s_per_rank"]) == 2
 
 
-def test_two_rank_sweep_with_pull_scheduling(tmp_path):
-    """schedule="dynamic" (the reference's pull scheduling, remo3d.py:843-860): every batch is drawn exactly once from
-    the shared counter; the rank that is made slow ends up with fewer batches; logs identical to the static sweep."""
-    res = _run_two_ranks(tmp_path, "dynamic")
-    n = res[0]["n_batches"]
-    assert res[0]["taken"] + res[1]["taken"] == n
-    assert res[0]["calls"] + res[1]["calls"] == n
-    slow = res[0] if res[0]["rank"] == 0 else res[1]
-    fast = res[1] if res[0]["rank"] == 0 else res[0]
-    assert slow["taken"] < fast["taken"], (slow["taken"], fast["taken"])
-    _check_logs(res)
-    assert res[0]["timing"]["failed_batches"] + res[1]["timing"]["failed_batches"] == 1
+def test_rank_that_pulls_nothing_still_joins_the_collectives(tmp_path):
+    """A sweep of ONE batch under the pull schedule: one rank draws it, the other draws nothing and must still take part in
+    the completeness check, the all-reduce of the logs and the gather of the busy times (no hang, complete logs on both)."""
+    res = _run_two_ranks(tmp_path, "dynamic", "one_batch")
+    assert res[0]["n_batches"] == 1
+    assert sorted(r["taken"] for r in res) == [0, 1]
+    for tool in res[0]["logs"]:
+        a = np.array(res[0]["logs"][tool]); b = np.array(res[1]["logs"][tool])
+        assert np.array_equal(a, b) and np.allclose(a[:, 1], 7.0, rtol=1e-12)
+
+
+def test_programming_error_on_one_rank_does_not_hang_the_others(tmp_path):
+    """A TypeError inside one batch (here: from the mesh provider) is recorded as a failed batch, the rank still reaches the
+    collectives, and only then raises it (a rank that raised at once left the others in the all-reduce)."""
+    res = _run_two_ranks(tmp_path, "static", "type_error")
+    raised = [r["raised"] for r in sorted(res, key=lambda r: r["rank"])]
+    assert raised == [None, "TypeError"]          # batch 3 belongs to rank 1
+    n_nan = 0
+    for tool in res[0]["logs"]:                   # the logs were combined before the error was raised
+        a = np.array(res[0]["logs"][tool]); b = np.array(res[1]["logs"][tool])
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        good = ~np.isnan(a[:, 1])
+        n_nan += int((~good).sum())
+        assert np.allclose(a[good, 1], 7.0, rtol=1e-12) and np.allclose(b[good, 1], 7.0, rtol=1e-12)
+    assert 0 < n_nan <= 4 * 3                     # exactly the records of the failed batch

@@ -70,6 +70,27 @@ template <class T> struct ElemOpT {
 };
 void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s);
 
+// Patch operator (3D, remo_opts_t.op = 3; patch.hip): the element list cut into runs of E elements, one workgroup each
+struct PatchTables {
+    int64_t nt = 0, n = 0, npatch = 0;
+    int E = 0;                         // elements per patch = 256 / right-hand sides of the batch (one lane per element and column)
+    int rows_cap = 0;                  // rows of prow / pout per patch
+    const uint16_t *lidx = nullptr;    // [nt][20] local row of every element dof inside its patch, 0xFFFF = constrained
+    const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
+    const int32_t *prow = nullptr;     // [npatch][rows_cap] matrix row of local row m, ascending
+    const int32_t *pout = nullptr;     // [npatch][rows_cap] -1: the row belongs to this patch alone (result goes to y); else its slot in the boundary slab
+    const int32_t *bptr = nullptr;     // [n + 1] entries [bptr[r], bptr[r + 1]) of bslot belong to row r, one per patch that touches it (none: not shared)
+    const int32_t *bslot = nullptr;    // slab slot of each (row, patch) pair; the slab itself is patch-major (a patch's shared rows are one block)
+    const double *C = nullptr;         // [nt][6] metric terms (launch_metric_terms)
+    int64_t nslot_cap = 0;             // upper bound of bptr[n]: rows of the slab
+};
+template <class T> struct PatchOpT {
+    PatchTables t;
+    T *Yb = nullptr;                   // [nslot_cap][k] boundary slab
+    double *ppart = nullptr;           // [npatch][8] <x, y> of every patch's own rows
+    int lds_rows = 0;                  // largest pcount: sizes the kernel's LDS
+};
+
 template <class T> struct CsrViewT {
     int64_t n;
     int64_t nnz;
@@ -80,10 +101,11 @@ template <class T> struct CsrViewT {
     // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
     const ElemOpT<T> *elem = nullptr;   // != nullptr: launch_spmm applies the element-wise operator instead of the stored entries
+    const PatchOpT<T> *patch = nullptr; // != nullptr: launch_spmm applies the patch operator (patch.hip)
 };
 using CsrView = CsrViewT<double>;
 
-void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,
+void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat, const int32_t *eperm /* or null */,
                          const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s);
 // rows [pair_begin, pair_end) (the two dofs of every free edge) get their values interleaved: entry e of the first row
 // at rowptr[row] + 2e, of the second at rowptr[row] + 2e + 1 (CsrViewT below); all other rows plain CSR
@@ -99,6 +121,10 @@ int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
 // scal != nullptr: the launch belongs to PCG step `step` and returns at once when an earlier step froze every column
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step = 0);
+
+template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step);   // patch.hip
+void set_patch_mode(int mode);
+int patch_elements_per_group(int kmax);
 
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)

@@ -12,69 +12,9 @@
 
 #include "fem_p3.h"
 #include "wave_util.h"
+#include "kutil.h"
 
 namespace remo {
-
-// Sum K per-thread values over the block (blockDim.x multiple of 64, <= 1024).  Result valid in
-// every thread.  Deterministic: fixed tree.
-template <int K> __device__ __forceinline__ void block_sum(double (&v)[K], double *smem /* [16*K] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int c = 0; c < K; ++c) v[c] = wave_sum(v[c]);
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-        for (int c = 0; c < K; ++c) smem[wave * K + c] = v[c];
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < K; ++c) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += smem[w * K + c];
-        v[c] = s;
-    }
-}
-
-// Sum of per-block partials part[nb][K] in a fixed order; result in every thread.
-template <int K> __device__ __forceinline__ void reduce_partials(const double *part, int nb, double (&out)[K], double *smem) {
-    double v[K];
-#pragma unroll
-    for (int c = 0; c < K; ++c) v[c] = 0.0;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x)
-#pragma unroll
-        for (int c = 0; c < K; ++c) v[c] += part[b * K + c];
-    block_sum<K>(v, smem);
-#pragma unroll
-    for (int c = 0; c < K; ++c) out[c] = v[c];
-}
-
-// Up to three partial arrays reduced in ONE pass (one barrier pair instead of three): the loads of all
-// arrays are in flight together.  Arrays with n = 0 are skipped.  Fixed order: deterministic.
-template <int K>
-__device__ __forceinline__ void reduce_partials3(const double *pa, int na, const double *pb, int nb, const double *pc, int nc,
-                                                 double (&oa)[K], double (&ob)[K], double (&oc)[K], double *smem /* [16*3*K] */) {
-    double v[3 * K];
-#pragma unroll
-    for (int c = 0; c < 3 * K; ++c) v[c] = 0.0;
-    for (int b = threadIdx.x; b < na; b += blockDim.x)
-#pragma unroll
-        for (int c = 0; c < K; ++c) v[c] += pa[b * K + c];
-    for (int b = threadIdx.x; b < nb; b += blockDim.x)
-#pragma unroll
-        for (int c = 0; c < K; ++c) v[K + c] += pb[b * K + c];
-    for (int b = threadIdx.x; b < nc; b += blockDim.x)
-#pragma unroll
-        for (int c = 0; c < K; ++c) v[2 * K + c] += pc[b * K + c];
-    block_sum<3 * K>(v, smem);
-#pragma unroll
-    for (int c = 0; c < K; ++c) { oa[c] = v[c]; ob[c] = v[K + c]; oc[c] = v[2 * K + c]; }
-}
-
-template <int K> __device__ __forceinline__ double pick(const double (&a)[K], int c) {
-    double r = a[0];
-#pragma unroll
-    for (int j = 1; j < K; ++j) r = (c == j) ? a[j] : r;
-    return r;
-}
 
 // Progress records live in mapped, coherent host memory: the stores bypass the caches (sc0 sc1).  A system-scope RELEASE
 // store would also write back the whole L2 of the XCD (buffer_wbl2) on every PCG step; the record only needs its data to
@@ -95,16 +35,6 @@ __device__ __forceinline__ int64_t value_pos(int64_t row, int32_t rs, int32_t le
     return int64_t(second ? rs - len : rs) + 2 * int64_t(e) + (second ? 1 : 0);
 }
 
-// scal[kDoneSlot] (as int) is set to s + 1 by the update launch of step s once every column is frozen; the launches of
-// LATER steps that the host has already queued (it runs a few steps ahead of the device) then return at once.  The
-// launches of step s itself (the update that raises the flag included) never act on it: a workgroup whose waves start
-// on both sides of the store would otherwise split, the early leavers missing from the block sums of the rest.  They
-// run a harmless step instead (alpha = beta = 0 for every column).
-__device__ __forceinline__ bool solve_done(const double *scal, int step) {
-    const int d = reinterpret_cast<const int *>(scal + kDoneSlot)[0];
-    return d != 0 && d <= step;
-}
-
 // ------------------------------------------------------------------------------------------
 // metric terms: one thread per element (ngsolve_functions.py:33-36: the coefficient part of the
 // integrand; sigma per material as worker.py:101)
@@ -112,8 +42,8 @@ __device__ __forceinline__ bool solve_done(const double *scal, int step) {
 template <int DIM>
 __global__ void __launch_bounds__(256) k_metric_terms(int64_t nt, const double *__restrict__ coords,
                                                       const int32_t *__restrict__ conn, const int32_t *__restrict__ mat,
-                                                      const double *__restrict__ sigma, int nmat, double *__restrict__ C,
-                                                      int32_t *errflag) {
+                                                      const int32_t *__restrict__ eperm, const double *__restrict__ sigma, int nmat,
+                                                      double *__restrict__ C, int32_t *errflag) {
     constexpr int NB = DIM + 1, NT = P3<DIM>::NTERM;
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -124,7 +54,7 @@ __global__ void __launch_bounds__(256) k_metric_terms(int64_t nt, const double *
 #pragma unroll
         for (int k = 0; k < DIM; ++k) X[a * DIM + k] = coords[v * DIM + k];
     }
-    const int m = mat[t];
+    const int m = mat[eperm ? int64_t(eperm[t]) : t];   // materials stay in the caller's element order (symbolic_gpu.hip)
     double c[NT];
     bool ok = (m >= 0 && m < nmat);
     if (ok) ok = metric_terms<DIM>(X, sigma[m], c);
@@ -137,13 +67,13 @@ __global__ void __launch_bounds__(256) k_metric_terms(int64_t nt, const double *
     for (int i = 0; i < NT; ++i) C[t * NT + i] = c[i];
 }
 
-void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat,
+void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_t *conn, const int32_t *mat, const int32_t *eperm,
                          const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s) {
     const int grid = int((nt + 255) / 256);
     if (dim == 2)
-        hipLaunchKernelGGL(k_metric_terms<2>, dim3(grid), dim3(256), 0, s, nt, coords, conn, mat, sigma, nmat, C, errflag);
+        hipLaunchKernelGGL(k_metric_terms<2>, dim3(grid), dim3(256), 0, s, nt, coords, conn, mat, eperm, sigma, nmat, C, errflag);
     else
-        hipLaunchKernelGGL(k_metric_terms<3>, dim3(grid), dim3(256), 0, s, nt, coords, conn, mat, sigma, nmat, C, errflag);
+        hipLaunchKernelGGL(k_metric_terms<3>, dim3(grid), dim3(256), 0, s, nt, coords, conn, mat, eperm, sigma, nmat, C, errflag);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -553,49 +483,6 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 // of 2.6 kB of matrix: the work moves from the vector-memory path, which bounds the CSR kernel, to the fp64 pipes.
 #include "build/elem_apply.inc"
 
-// ---- buffer accesses with the hardware range check: a lane with nothing to load / store hands the instruction an offset
-// beyond the descriptor's range - the load returns 0, the store is dropped, and neither sends a request down the
-// vector-memory path.  No branch around the access, so the compiler keeps all of them in flight together.
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr uint32_t kOutOfRange = 0xFFFFF000u;   // beyond any descriptor the launcher accepts
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, int(uint32_t(bytes)), 0x00020000);
-}
-template <class T, int N> __device__ __forceinline__ void buf_load(rsrc_t r, uint32_t off, T (&out)[N]) {   // N values from byte offset off (multiple of 4)
-    constexpr int W = N * int(sizeof(T)) / 4;
-    unsigned int w[W];
-    int d = 0;
-#pragma unroll
-    for (; d + 4 <= W; d += 4) {
-        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, off + 4u * d, 0, 0);
-        w[d] = q.x; w[d + 1] = q.y; w[d + 2] = q.z; w[d + 3] = q.w;
-    }
-    if constexpr ((W & 3) >= 2) {
-        const u32x2_t q = __builtin_amdgcn_raw_buffer_load_b64(r, off + 4u * (W & ~3), 0, 0);
-        w[W & ~3] = q.x; w[(W & ~3) + 1] = q.y;
-    }
-    if constexpr (W & 1) w[W - 1] = __builtin_amdgcn_raw_buffer_load_b32(r, off + 4u * (W - 1), 0, 0);
-    __builtin_memcpy(out, w, sizeof(T) * N);
-}
-template <class T, int N> __device__ __forceinline__ void buf_store(rsrc_t r, uint32_t off, const T (&in)[N]) {
-    constexpr int W = N * int(sizeof(T)) / 4;
-    unsigned int w[W];
-    __builtin_memcpy(w, in, sizeof(T) * N);
-    int d = 0;
-#pragma unroll
-    for (; d + 4 <= W; d += 4) {
-        u32x4_t q; q.x = w[d]; q.y = w[d + 1]; q.z = w[d + 2]; q.w = w[d + 3];
-        __builtin_amdgcn_raw_buffer_store_b128(q, r, off + 4u * d, 0, 0);
-    }
-    if constexpr ((W & 3) >= 2) {
-        u32x2_t q; q.x = w[W & ~3]; q.y = w[(W & ~3) + 1];
-        __builtin_amdgcn_raw_buffer_store_b64(q, r, off + 4u * (W & ~3), 0, 0);
-    }
-    if constexpr (W & 1) __builtin_amdgcn_raw_buffer_store_b32(w[W - 1], r, off + 4u * (W - 1), 0, 0);
-}
-
 // slot[t * 20 + li] = position of (element t, local dof li) in the row-sorted adjacency list, -1 for constrained dofs: where
 // pass 1 puts an element's result rows so that pass 2 finds the contributions of a matrix row side by side
 __global__ void __launch_bounds__(256) k_elem_slots(int64_t n, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj, int32_t *__restrict__ slot) {
@@ -821,6 +708,12 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 }
 
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
+    // patch operator (patch.hip): its tables are laid out for the batch's own column count - a product with more columns than
+    // that (inspection hooks only) goes through the stored matrix
+    if (A.patch && k * A.patch->t.E <= 256 && size_t(A.patch->lds_rows + 2) * k * sizeof(T) <= 60 * 1024) {
+        launch_patch_spmm(A, k, x, y, part, scal, nb, s, step);
+        return;
+    }
     if (A.elem) {     // element-wise operator instead of the stored matrix
         switch (k) {
             case 1: elem_dispatch<T, 1>(A, x, y, part, scal, step, nb, s); break;

@@ -1,0 +1,458 @@
+// patch.hip — the patch operator (3D, remo_opts_t.op = 3): y = A x without the assembled matrix AND without a slab of element
+// results.  Replaces the operator application inside CGSolver(a.mat, ...) (ngsolve_functions.py:50-51); same operator as the
+// CSR product of the assembled matrix and as the element-wise operator of kernels.hip (k_elem_apply / k_elem_reduce) to rounding.
+//
+// The element list (sorted by smallest vertices, symbolic_gpu.hip: neighbours in the list are neighbours in the mesh) is cut into
+// PATCHES of E consecutive tetrahedra, one 256-thread workgroup each.  A patch touches ~7.5 distinct matrix rows per element
+// instead of 20 (E = 85), and 45 % of them belong to no other patch.  Per patch:
+//   1. the x rows of the patch's distinct dofs are staged in LDS - every row read once per patch, whole k-wide rows;
+//   2. lane (element, pair of right-hand sides) reads its 20 rows from LDS, runs the factorised reference tensors
+//      (gen_elem_code.cpp: g = B x, h = c~ g, y = B^T h - 492 multiply-adds per column) and adds its 20 result rows into LDS
+//      accumulators that REUSE the staging area (x lives in registers by then);
+//   3. rows interior to the patch go straight to y (and leave their share of <x, y>); rows shared with other patches go to a
+//      compact boundary slab, one slot per (row, patch), which k_patch_reduce sums in ascending patch order.
+// HBM / L2 traffic per application: ~1.6 x-rows and ~2.5 y-rows of k values per matrix row plus 88 bytes per element, against
+// 12 bytes per STORED ENTRY of the CSR product (48 entries per row) and against two passes over a 20-rows-per-element slab in the
+// element-wise operator.  The LDS accumulation uses ds_add_f64 / ds_add_f32: the order of the adds inside a patch is not fixed,
+// so results are reproducible to rounding (1e-16 relative per row), not bit for bit - the one kernel of the path for which that holds.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "kernels.h"
+#include "kutil.h"
+#include "patch.h"
+#include "symbolic_gpu.h"
+#include "wave_util.h"
+
+#include "build/elem_apply.inc"
+
+namespace remo {
+
+namespace {
+
+constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192
+constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
+
+// ---- tables ------------------------------------------------------------------------------------------------------------
+// bcnt[r] = number of patches that touch row r if there are at least two (the row gets that many slots in the boundary slab),
+// else 0.  The adjacency of a row lists its elements in ascending order, so its patches ascend too.
+__global__ void __launch_bounds__(256) k_patch_row_slots(int64_t n, int E, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
+                                                         int32_t *__restrict__ bcnt) {
+    const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    int cnt = 0;
+    if (r < n) {
+        int32_t last = -1;
+        for (int32_t a = adjptr[r]; a < adjptr[r + 1]; ++a) {
+            const int32_t p = int32_t((adj[a] >> 5) / uint32_t(E));
+            cnt += p != last;
+            last = p;
+        }
+    }
+    bcnt[r] = cnt >= 2 ? cnt : 0;
+}
+
+// One workgroup per patch: sort the patch's (row, element dof slot) pairs in LDS, number the distinct rows 0 .. M - 1 in
+// ascending order, and write
+//   lidx[element dof]  local row (0xFFFF: constrained dof)
+//   prow[p][m]         global row of local row m
+//   pout[p][m]         -1 if every element of the row is in this patch, else the row's slot in the boundary slab
+//   pcount[p] = M      (raises flag bit 1 and records nothing beyond rows_cap if M > rows_cap)
+__global__ void __launch_bounds__(256) k_patch_build(int64_t nt, int E, int rows_cap, int npad, const int32_t *__restrict__ eldof,
+                                                     const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
+                                                     uint16_t *__restrict__ lidx, int32_t *__restrict__ pcount, int32_t *__restrict__ pbcnt,
+                                                     int32_t *__restrict__ prow, int32_t *__restrict__ pout, int32_t *flag, int32_t *max_rows) {
+    extern __shared__ uint64_t keys[];   // [npad]
+    __shared__ int32_t cnts[256];
+    const int tid = threadIdx.x;
+    const int64_t p = blockIdx.x, e0 = p * E;
+    const int ne = int(nt - e0 < E ? nt - e0 : E), nslots = ne * 20;
+    for (int j = tid; j < npad; j += 256) {
+        uint64_t k = ~uint64_t(0);
+        if (j < nslots) {
+            const int32_t r = eldof[e0 * 20 + j];
+            k = ((r >= 0 ? uint64_t(uint32_t(r)) : kNoRow) << kSlotBits) | uint64_t(j);
+        }
+        keys[j] = k;
+    }
+    for (int size = 2; size <= npad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < npad / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    __syncthreads();
+    const int per = npad / 256, j0 = tid * per;
+    auto row_at = [&](int j) -> uint64_t { return keys[j] >> kSlotBits; };
+    int heads = 0;
+    for (int j = j0; j < j0 + per; ++j) {
+        const uint64_t r = row_at(j);
+        heads += (j < nslots && r < kNoRow && (j == 0 || row_at(j - 1) != r)) ? 1 : 0;
+    }
+    cnts[tid] = heads;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int t = 0; t < 256; ++t) { const int c = cnts[t]; before += t < tid ? c : 0; total += c; }
+    if (tid == 0) {
+        pcount[p] = total;
+        atomicMax(max_rows, total);
+        if (total > rows_cap) atomicOr(flag, 1);
+    }
+    int id = before - 1;     // local row of the most recent head at or before j
+    int shared = 0;          // heads of this lane's chunk whose row is also touched by elements of other patches
+    for (int j = j0; j < j0 + per && j < nslots; ++j) {
+        const uint64_t r = row_at(j);
+        const int slot = int(keys[j] & ((uint64_t(1) << kSlotBits) - 1));
+        if (r >= kNoRow) { lidx[e0 * 20 + slot] = 0xFFFF; continue; }
+        const bool head = (j == 0 || row_at(j - 1) != r);
+        id += head ? 1 : 0;
+        lidx[e0 * 20 + slot] = uint16_t(id < 0xFFFF ? id : 0xFFFE);
+        if (head && id < rows_cap) {
+            int run = 1;
+            while (j + run < nslots && row_at(j + run) == r) ++run;
+            const int32_t row = int32_t(r);
+            const bool is_shared = run != adjptr[row + 1] - adjptr[row];
+            prow[p * rows_cap + id] = row;
+            pout[p * rows_cap + id] = is_shared ? 0 : -1;     // k_patch_slots numbers the shared rows
+            shared += is_shared ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    cnts[tid] = shared;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int q = 0; q < 256; ++q) t += cnts[q];
+        pbcnt[p] = t;
+    }
+}
+
+// Slab slots.  The slab is PATCH-major: the shared rows of patch p own the slots pboff[p], pboff[p] + 1, ... in ascending row order,
+// so a patch writes one contiguous block, and the rows of a block read by k_patch_reduce are neighbours too.  One workgroup per
+// patch: pout[p][m] = slot of local row m (-1 stays: not shared), and the row's list bslot[bptr[row] + rank of this patch among the
+// patches of the row] = that slot.
+__global__ void __launch_bounds__(256) k_patch_slots(int E, int rows_cap, const int32_t *__restrict__ pcount, const int32_t *__restrict__ pboff,
+                                                     const int32_t *__restrict__ prow, int32_t *__restrict__ pout, const int32_t *__restrict__ adjptr,
+                                                     const uint32_t *__restrict__ adj, const int32_t *__restrict__ bptr, int32_t *__restrict__ bslot) {
+    __shared__ int32_t cnts[256];
+    const int tid = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    const int mp = pcount[p] < rows_cap ? pcount[p] : rows_cap;
+    const int per = (mp + 255) / 256, m0 = tid * per;
+    int mine = 0;
+    for (int m = m0; m < m0 + per && m < mp; ++m) mine += pout[p * rows_cap + m] >= 0 ? 1 : 0;
+    cnts[tid] = mine;
+    __syncthreads();
+    int before = 0;
+    for (int t = 0; t < tid; ++t) before += cnts[t];
+    int32_t slot = pboff[p] + before;
+    for (int m = m0; m < m0 + per && m < mp; ++m) {
+        if (pout[p * rows_cap + m] < 0) continue;
+        const int32_t row = prow[p * rows_cap + m];
+        int32_t last = -1, rank = 0;
+        for (int32_t a = adjptr[row]; a < adjptr[row + 1]; ++a) {     // patches of the row ascend with its elements
+            const int32_t q = int32_t((adj[a] >> 5) / uint32_t(E));
+            if (q >= p) break;
+            rank += q != last;
+            last = q;
+        }
+        pout[p * rows_cap + m] = slot;
+        bslot[bptr[row] + rank] = slot;
+        ++slot;
+    }
+}
+
+// ---- apply ---------------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One workgroup = one patch of E = 256 / K elements; lane = (element, right-hand side).
+// The kernel is a chain of dependent memory round trips (tables -> x rows -> LDS -> ... -> stores) around ~1 us of arithmetic, so
+// everything a lane will need from the tables is requested BEFORE the first wait - the rows it stages and later writes out (two
+// per lane in registers; prow holds -1 behind a patch's last row, so no row count is needed first), where their results go, the
+// local rows of its element, the metric terms - which leaves two round trips: tables, then x.
+// <x, A x> is summed element by element as g . h (g = B x, h = c~ g: x^T B^T c~ B x): complete when this launch ends, no second
+// look at x.  MODE != 0: ablations for tools/probe_patch.py (wrong results on purpose): 1 = plain stores instead of the LDS
+// atomics, 2 = no tensor arithmetic (y = x), 3 = nothing leaves the workgroup.
+template <class T, int K, int MODE = 0>
+__global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+                                                     double *__restrict__ ppart, const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
+    constexpr int NL = K;
+    constexpr int U = 4;                                 // independent loads in flight per lane and trip
+    extern __shared__ double lds_raw[];
+    T *xs = reinterpret_cast<T *>(lds_raw);              // [(rows + 2)][K]: x rows, later the accumulators of y; row `rows` = zeros
+    __shared__ double smem[16 * K];
+    const int tid = threadIdx.x;
+    // workgroups b, b + 8, ... share an XCD and its L2: every XCD takes one contiguous eighth of the patches (neighbouring patches
+    // share their boundary rows: the second reader finds them in that L2, and the slab rows of one matrix row are written through it)
+    const int64_t per = (tb.npatch + 7) >> 3;
+    const int64_t p = int64_t(blockIdx.x & 7) * per + int64_t(blockIdx.x >> 3);
+    if (p >= tb.npatch) return;
+    const int32_t *prow = tb.prow + p * tb.rows_cap, *pout = tb.pout + p * tb.rows_cap;
+    const int el = tid / NL, c0 = tid - el * NL;
+    const int64_t e = p * tb.E + el;
+    const bool active = el < tb.E && e < tb.nt;
+    uint32_t li[10];
+    double cm[6];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) li[q] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) cm[q] = 0.0;
+    if (active) {
+        const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);   // 40-byte records: 8-byte aligned
+#pragma unroll
+        for (int q = 0; q < 10; ++q) li[q] = pl[q];
+        const double *ce = tb.C + e * 6;                               // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+    }
+    // 1. stage the patch's x rows, ONE VALUE per lane and pass: lane j takes value j of the staged image, so neighbouring lanes
+    // read neighbouring addresses inside a row and across consecutive rows (a patch's rows come in a few runs of consecutive
+    // matrix rows) - a wave's load covers a handful of cache lines.  (A k-wide row per lane spreads every load instruction of a
+    // wave over 20-40 lines, three instructions per row: that, not the arithmetic, was the kernel time.)  prow holds -1 behind a
+    // patch's last row, so no row count has to arrive first.  Row `rows` is the zero row constrained dofs read (and add into).
+    const int nw = rows * K;
+    for (int j0 = tid; j0 < nw; j0 += U * 256) {
+        int32_t r[U];
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 256 * u;
+            r[u] = j < nw ? prow[j / K] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 256 * u;
+            v[u] = r[u] >= 0 ? x[int64_t(r[u]) * K + (j % K)] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 256 * u;
+            if (j < nw) xs[j] = v[u];
+        }
+    }
+    if (tid < 2 * K) xs[rows * K + tid] = T(0);
+    __syncthreads();
+    // 2. my element, my column
+    T xv[20];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            l = l == 0xFFFFu ? uint32_t(rows) : l;
+            xv[i] = xs[l * K + c0];
+        }
+    }
+    __syncthreads();        // every lane holds its x values: the staging area becomes the accumulators
+    for (int j = tid; j < (rows + 1) * K; j += 256) xs[j] = T(0);
+    __syncthreads();
+    double d0 = 0.0;
+    if (active) {
+        const T c11 = T(cm[0]), c12 = T(cm[1]), c13 = T(cm[2]), c22 = T(cm[3]), c23 = T(cm[4]), c33 = T(cm[5]);
+        T g[30], yv[20];
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) yv[i] = xv[i] * c11;
+        } else {
+            REMO_ELEM_GRAD(T, xv, g)
+            T dd = T(0);
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
+                const T g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
+                const T h1 = c11 * g1 + c12 * g2 + c13 * g3, h2 = c12 * g1 + c22 * g2 + c23 * g3, h3 = c13 * g1 + c23 * g2 + c33 * g3;
+                dd += g1 * h1 + g2 * h2 + g3 * h3;
+                g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
+            }
+            d0 = double(dd);
+            REMO_ELEM_DIV(T, g, yv)
+        }
+        // the local rows are read a second time for the accumulation (an L1 / L2 hit) instead of being held in ten registers
+        // through the tensor arithmetic: that is the difference between three and four waves per SIMD in fp64
+        {
+            const uint32_t *pl2 = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) li[q] = __builtin_nontemporal_load(pl2 + q);
+        }
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+            uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            l = l == 0xFFFFu ? uint32_t(rows) : l;
+            if constexpr (MODE == 1) xs[l * K + c0] = yv[i];
+            else lds_add(xs + l * K + c0, yv[i]);
+        }
+    }
+    __syncthreads();
+    // 3. rows of this patch alone -> y; shared rows -> the patch's block of the boundary slab; one value per lane and pass again
+    if constexpr (MODE != 3) {
+        for (int j0 = tid; j0 < nw; j0 += U * 256) {
+            int32_t r[U], o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                r[u] = j < nw ? prow[j / K] : -1;
+                o[u] = j < nw ? pout[j / K] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 256 * u;
+                if (r[u] >= 0) {
+                    T *dst = o[u] < 0 ? y + int64_t(r[u]) * K : Yb + int64_t(o[u]) * K;
+                    dst[j % K] = xs[j];
+                }
+            }
+        }
+    }
+    if (ppart) {
+        double dot[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
+        block_sum<K>(dot, smem);
+        if (tid < K) ppart[p * K + tid] = pick<K>(dot, tid);
+    }
+}
+
+// Rows shared by several patches: sum of the row's slab slots in ascending patch order.  DOT: the patches' <x, A x> are folded
+// into <= 1024 partial rows for the consumer (every workgroup takes a fixed subset: deterministic given the patches' sums).
+template <class T, int K, bool DOT>
+__global__ void __launch_bounds__(256) k_patch_reduce(int64_t n, int64_t npatch, const int32_t *__restrict__ bptr, const int32_t *__restrict__ bslot,
+                                                      const T *__restrict__ Yb,
+                                                      T *__restrict__ y, const double *__restrict__ ppart,
+                                                      double *__restrict__ part, const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+        const int32_t b0 = bptr[row], b1 = bptr[row + 1];
+        if (b1 <= b0) continue;
+        T acc[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[c] = T(0);
+        for (int32_t s0 = b0; s0 < b1; s0 += 2) {     // two slots in flight (a row has 2-4), ascending patches
+            T v0[K], v1[K];
+            const bool second = s0 + 1 < b1;
+            const int64_t a0 = bslot[s0], a1 = second ? bslot[s0 + 1] : 0;
+#pragma unroll
+            for (int c = 0; c < K; ++c) v0[c] = Yb[a0 * K + c];
+#pragma unroll
+            for (int c = 0; c < K; ++c) v1[c] = second ? Yb[a1 * K + c] : T(0);
+#pragma unroll
+            for (int c = 0; c < K; ++c) acc[c] = (acc[c] + v0[c]) + v1[c];
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) y[row * K + c] = acc[c];
+    }
+    if (DOT) {
+        double dot[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dot[c] = 0.0;
+        for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < npatch; p += stride)
+#pragma unroll
+            for (int c = 0; c < K; ++c) dot[c] += ppart[p * K + c];
+        __shared__ double smem[16 * K];
+        block_sum<K>(dot, smem);
+        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
+    }
+}
+
+int g_patch_mode = 0;  // key 21: ablation mode of k_patch_apply (fp64, k = 5 only)
+
+}  // namespace
+
+void set_patch_mode(int mode) { g_patch_mode = mode; }
+
+int patch_elements_per_group(int kmax) { return 256 / (kmax > 0 ? kmax : 1); }   // one lane per (element, right-hand side)
+
+size_t patch_arena_bytes(int64_t nt, int64_t n_max, int kmax) {
+    const int E = patch_elements_per_group(kmax);
+    const int64_t npatch = (nt + E - 1) / E;
+    const int64_t cap = int64_t(E) * 20;
+    return size_t(nt) * 40 + size_t(npatch) * (16 + 12 * size_t(cap)) + size_t(n_max + 2) * 8 + size_t(npatch) * 8 * 8 + (1 << 20);
+}
+
+// Everything is enqueued on s; flag_and_max (device, two ints) must be read by the caller after its next synchronisation:
+// [0] != 0 -> a patch has more distinct rows than the tables hold (the caller falls back to another operator), [1] = the
+// largest row count (sizes the kernel's LDS).
+void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, const double *C, int kmax, PatchTables &out, int32_t *flag_and_max) {
+    out = PatchTables{};
+    const int64_t nt = sy.nt, n = sy.nfree;
+    const int E = patch_elements_per_group(kmax);
+    // rows a patch may hold: what fits the LDS budget of one workgroup (48 KB of k-wide fp64 rows), at most every dof distinct
+    int rows_cap = int((48 * 1024) / (size_t(kmax) * 8)) - 2;
+    if (rows_cap > E * 20) rows_cap = E * 20;
+    int npad = 256;
+    while (npad < E * 20) npad <<= 1;
+    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap;
+    out.npatch = (nt + E - 1) / E;
+    out.C = C;
+    uint16_t *lidx = ar.lo<uint16_t>(size_t(nt) * 20 + 8);
+    int32_t *pcount = ar.lo<int32_t>(size_t(out.npatch) + 1);
+    int32_t *prow = ar.lo<int32_t>(size_t(out.npatch) * rows_cap + 1);
+    int32_t *pout = ar.lo<int32_t>(size_t(out.npatch) * rows_cap + 1);
+    int32_t *bptr = ar.lo<int32_t>(size_t(n) + 2);
+    out.nslot_cap = out.npatch * int64_t(rows_cap) < nt * 20 ? out.npatch * int64_t(rows_cap) : nt * 20;
+    int32_t *bslot = ar.lo<int32_t>(size_t(out.nslot_cap) + 2);
+    const size_t mark = ar.hi_mark();
+    int32_t *bcnt = ar.hi<int32_t>(size_t(n) + 2);
+    int32_t *pbcnt = ar.hi<int32_t>(size_t(out.npatch) + 2), *pboff = ar.hi<int32_t>(size_t(out.npatch) + 2);
+    (void)hipMemsetAsync(flag_and_max, 0, 2 * sizeof(int32_t), s);
+    (void)hipMemsetAsync(prow, 0xFF, sizeof(int32_t) * (size_t(out.npatch) * rows_cap + 1), s);   // -1 behind a patch's last row
+    (void)hipMemsetAsync(pbcnt + out.npatch, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt);
+    hipLaunchKernelGGL(k_patch_build, dim3(int(out.npatch)), dim3(256), size_t(npad) * 8, s, nt, E, rows_cap, npad, sy.eldof, sy.adjptr, sy.adj,
+                       lidx, pcount, pbcnt, prow, pout, flag_and_max, flag_and_max + 1);
+    size_t tb1 = 0, tb2 = 0;
+    (void)rocprim::exclusive_scan(nullptr, tb1, bcnt, bptr, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s);
+    (void)rocprim::exclusive_scan(nullptr, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
+    void *tmp = ar.hi<char>((tb1 > tb2 ? tb1 : tb2) + 256);
+    (void)rocprim::exclusive_scan(tmp, tb1, bcnt, bptr, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s);
+    (void)rocprim::exclusive_scan(tmp, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
+    hipLaunchKernelGGL(k_patch_slots, dim3(int(out.npatch)), dim3(256), 0, s, E, rows_cap, (const int32_t *)pcount, (const int32_t *)pboff, (const int32_t *)prow, pout,
+                       sy.adjptr, sy.adj, (const int32_t *)bptr, bslot);
+    ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
+    out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.bptr = bptr; out.bslot = bslot;
+}
+
+template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
+    const PatchOpT<T> &P = *A.patch;
+    const PatchTables &tb = P.t;
+    const int64_t per = (tb.npatch + 7) / 8;
+    const size_t lds = size_t(P.lds_rows + 2) * K * sizeof(T);
+    double *pp = part ? P.ppart : nullptr;
+    bool launched = false;
+    const dim3 grid(int(per * 8));
+    if constexpr (K == 5 && sizeof(T) == 8) {     // ablations (tools/probe_patch.py)
+        if (g_patch_mode >= 1 && g_patch_mode <= 3) {
+            launched = true;
+            if (g_patch_mode == 1) hipLaunchKernelGGL((k_patch_apply<T, 5, 1>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+            else if (g_patch_mode == 2) hipLaunchKernelGGL((k_patch_apply<T, 5, 2>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+            else hipLaunchKernelGGL((k_patch_apply<T, 5, 3>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+        }
+    }
+    if (!launched) hipLaunchKernelGGL((k_patch_apply<T, K>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+    if (part) hipLaunchKernelGGL((k_patch_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)P.ppart, part, scal, step);
+    else hipLaunchKernelGGL((k_patch_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)nullptr, part, scal, step);
+}
+
+template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
+    switch (k) {
+        case 1: patch_dispatch<T, 1>(A, x, y, part, scal, step, nb, s); break;
+        case 2: patch_dispatch<T, 2>(A, x, y, part, scal, step, nb, s); break;
+        case 3: patch_dispatch<T, 3>(A, x, y, part, scal, step, nb, s); break;
+        case 4: patch_dispatch<T, 4>(A, x, y, part, scal, step, nb, s); break;
+        case 5: patch_dispatch<T, 5>(A, x, y, part, scal, step, nb, s); break;
+        case 6: patch_dispatch<T, 6>(A, x, y, part, scal, step, nb, s); break;
+        case 7: patch_dispatch<T, 7>(A, x, y, part, scal, step, nb, s); break;
+        default: patch_dispatch<T, 8>(A, x, y, part, scal, step, nb, s); break;
+    }
+}
+template void launch_patch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int);
+template void launch_patch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int);
+
+}  // namespace remo

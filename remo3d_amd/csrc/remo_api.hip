@@ -23,6 +23,7 @@
 #include "fem_p3.h"
 #include "kernels.h"
 #include "amg.h"
+#include "patch.h"
 #include "symbolic.h"
 #include "symbolic_gpu.h"
 
@@ -111,6 +112,8 @@ struct remo_batch {
     double *d_f = nullptr;                  // load vectors [n][k_last] of the last chunk
     ElemOpT<double> elem64{};               // element-wise operator of the last run (remo_opts_t.op = 1), pointers into the arena
     ElemOpT<float> elem32{};
+    PatchOpT<double> patch64{};             // patch operator of the last run (remo_opts_t.op = 3), pointers into the arena
+    PatchOpT<float> patch32{};
     AmgT<double> amg64{};                   // multigrid hierarchy of the vertex block of the last run (arena)
     AmgT<float> amg32{};
     int k_last = 0;
@@ -142,6 +145,7 @@ int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row le
 int g_amg32 = 1;     // key 17: 1 = fp64 solves run the multigrid cycle in fp32 storage (default), 0 = in fp64
 int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
+int g_auto_patch = 1; // key 20: 1 = op 0 takes the patch operator in 3D whenever its tables fit (default), 0 = the round-2 choice by size
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
@@ -514,7 +518,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        if (o.op != 2 && dim == 3) need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;   // element result slab(s)
+        // element result slab(s) of the element-wise operator: when it is asked for, or may be chosen by size (the stored-entry
+        // count is only known after the numbering: nnz_max / 8 is a safe lower bound of what a 3D mesh produces)
+        if (dim == 3 && (o.op == 1 || (o.op == 0 && nnz_max / 8 > 17000000)))
+            need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;
+        const bool want_patch = dim == 3 && (o.op == 3 || o.op == 0);
+        if (want_patch) need += patch_arena_bytes(nt, ndof_max, kmax) + size_t(nt) * 20 * size_t(kmax) * 8;   // tables + boundary slab (upper bound)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
@@ -595,7 +604,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         // ---- assembly ---------------------------------------------------------------------
         const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
-        launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
+        launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, sy.eperm, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
         int64_t pair_begin = 0, pair_end = 0;   // edge-dof rows: consecutive pairs with identical patterns, values interleaved
         if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { pair_begin = sy.nvfree; pair_end = sy.nvefree; }
         launch_assemble(dim, sy.condense, n, pair_begin, pair_end, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
@@ -650,6 +659,15 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             HIP_TRY(hipMemcpyAsync(&h_vb[0], d_vbflag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&h_vb[1], vb_rowptr + nvc, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
+        // patch operator (patch.hip): its tables are built beside the assembly; their overflow flag and largest patch come
+        // back with the other small read-backs below
+        int32_t h_patch[2] = {1, 0};
+        PatchTables ptab{};
+        if (want_patch) {
+            int32_t *d_pflag = ctx->take<int32_t>(2);
+            build_patch_tables(ctx->ar, s, sy, d_C, kmax, ptab, d_pflag);
+            HIP_TRY(hipMemcpyAsync(h_patch, d_pflag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (want_compact && h_vb[0] == 0 && h_vb[1] > 0) { buf.vb_rowptr = vb_rowptr; buf.vb_col = vb_col; buf.vb_val = vb_val; }
@@ -695,8 +713,17 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // measured (bench, fp64, k = 5): 13.7 M stored entries CSR 49 us / element-wise 61; 21.6 M 102 / 78; 32.8 M 148 / 109; 93 M 472 / 381
         // (its buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
         const bool elem_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
-        const bool elem_op = dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
-        st->op_used = elem_op ? 1 : 0;
+        // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
+        // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits;
+        if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
+        const bool patch_op = patch_ok && (o.op == 3 || (o.op == 0 && g_auto_patch));
+        const bool elem_op = !patch_op && dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
+        st->op_used = patch_op ? 3 : (elem_op ? 1 : 0);
+        if (patch_op) {
+            b->patch64 = PatchOpT<double>{ptab, ctx->take<double>(size_t(ptab.nslot_cap) * size_t(kmax) + 8), ctx->take<double>(size_t(ptab.npatch) * 8 + 8), h_patch[1]};
+            b->A.patch = &b->patch64;
+        }
         if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
             int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);
             launch_elem_slots(n, nt, sy.adjptr, sy.adj, d_slot, s);
@@ -727,6 +754,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             launch_to_float(n, d_dinv, dinv32, s);
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
             mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
+            if (patch_op) {   // the slab and the partial sums are scratch of one application: the fp32 operator shares them
+                b->patch32 = PatchOpT<float>{ptab, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, h_patch[1]};
+                mx.A32.patch = &b->patch32;
+            }
             if (elem_op) {
                 b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, b->elem64.slot, nt * 20, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
                 mx.A32.elem = &b->elem32;
@@ -801,6 +832,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         st->ms_solve = ms_solve;
         st->spmv_bytes = mixed ? 8.0 * double(sy.nnz) + 4.0 * double(n) + 8.0 * double(kmax) * double(n)   // fp32 values and vectors
                                : 12.0 * double(sy.nnz) + 4.0 * double(n) + 16.0 * double(kmax) * double(n);
+        if (patch_op)   // the patch operator reads no stored entries: x and y once (k columns) + 40 bytes of local indices and 48 of metric terms per element
+            st->spmv_bytes = (mixed ? 8.0 : 16.0) * double(kmax) * double(n) + 88.0 * double(nt);
         if (o.time_kernels) {
             // what an event bracket measures beyond the enclosed kernel: an empty pair on the same stream
             float overhead = 1e30f;
@@ -1192,6 +1225,9 @@ void remo_debug_tune(int32_t key, int32_t value) {
     if (key == 6) g_square = value;
     else if (key == 7) g_sq_lanes = value;
     else if (key == 8) set_symbolic_tuning(value);
+    else if (key == 18) set_element_order(value);
+    else if (key == 20) g_auto_patch = value;
+    else if (key == 21) set_patch_mode(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

@@ -40,7 +40,8 @@ struct DeviceSymbolic {
     int64_t nv = 0, nt = 0, ne = 0, nf = 0, ndof = 0, nfree = 0, nnz = 0, nadj = 0;
     int64_t nvfree = 0;  // free vertex dofs: rows/cols [0, nvfree) are the P1 block of the matrix
     int64_t nvefree = 0; // free vertex + edge dofs: rows [nvfree, nvefree) are edge dofs, two consecutive rows per edge
-    int32_t *conn = nullptr;    // [nt][dim+1] ascending per element
+    int32_t *conn = nullptr;    // [nt][dim+1] ascending per element; elements sorted by their two smallest vertices
+    int32_t *eperm = nullptr;   // [nt] input element of element t (nullptr: input order kept)
     int32_t *eldof = nullptr;   // [nt][nld_full] free row or -1
     int32_t *freeid = nullptr;  // [ndof]
     int32_t *rowptr = nullptr;  // [nfree+1]
@@ -58,5 +59,6 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
 
 // probe hook: 0 = build the CSR pattern by the global sort instead of row by row
 void set_symbolic_tuning(int row_pattern);
+void set_element_order(int on);   // probe hook: 0 = keep the caller's element order
 
 }  // namespace remo

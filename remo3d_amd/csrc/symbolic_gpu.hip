@@ -65,6 +65,29 @@ __global__ void __launch_bounds__(256) k_sort_conn(int64_t nt, int64_t nv, const
     for (int a = 0; a < NB; ++a) out[t * NB + a] = c[a];
 }
 
+// Element order.  Vertices arrive in a locality-preserving (Morton) order from the meshers; elements arrive in whatever order
+// the triangulation produced them.  Sorting the elements by their two smallest vertices makes neighbours in the list neighbours
+// in the mesh: the element-wise kernels (assembly walk, metric terms, the patch operator of patch.hip, which cuts the list into
+// runs of elements that share most of their dofs) then touch compact ranges of the vectors.  eperm[t] = input element of sorted
+// element t (the material array stays in input order).
+template <int DIM>
+__global__ void __launch_bounds__(256) k_element_order_keys(int64_t nt, const int32_t *__restrict__ conn, int nbits, uint64_t *__restrict__ keys,
+                                                            int32_t *__restrict__ ids) {
+    const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    keys[t] = (uint64_t(uint32_t(conn[t * (DIM + 1)])) << nbits) | uint32_t(conn[t * (DIM + 1) + 1]);
+    ids[t] = int32_t(t);
+}
+template <int DIM>
+__global__ void __launch_bounds__(256) k_gather_conn(int64_t nt, const int32_t *__restrict__ in, const int32_t *__restrict__ perm,
+                                                     int32_t *__restrict__ out) {
+    const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const int64_t src = perm[t];
+#pragma unroll
+    for (int a = 0; a <= DIM; ++a) out[t * (DIM + 1) + a] = in[src * (DIM + 1) + a];
+}
+
 __device__ __forceinline__ uint64_t edge_key(int32_t a, int32_t b, int nbits) {
     if (a > b) { const int32_t t = a; a = b; b = t; }
     return (uint64_t(uint32_t(a)) << nbits) | uint32_t(b);
@@ -325,6 +348,7 @@ __global__ void __launch_bounds__(256) k_low32(int64_t n, int cbits, const uint6
 }
 
 int g_row_pattern = 1;   // 0: always build the pattern by sorting (A/B probe, set_symbolic_tuning)
+int g_element_order = 1; // 0: keep the caller's element order (A/B probe, set_element_order)
 inline int grid_for(int64_t n) { return int((n + 255) / 256); }
 inline int bits_for(uint64_t v) {  // bits needed to represent values 0..v
     int b = 1;
@@ -345,6 +369,7 @@ size_t symbolic_gpu_arena_bytes(int dim, int64_t nv, int64_t nt, int64_t nbf) {
     b += size_t(nt) * N * N * 4;                                                        // col (<= all pairs)
     b += size_t(nt) * N * N * 8 * 5;                                                    // COO keys in/sorted/unique + sort & select temporaries
     b += size_t(nt) * 10 * 8 * 4;                                                       // entity keys
+    b += size_t(nt) * (4 + (dim + 1) * 4 + 4 + 16 + 16);                                // element order: permutation, scratch
     b += 64 << 20;
     return b;
 }
@@ -370,8 +395,29 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     int32_t *d_cnt = ar.lo<int32_t>(8);           // [0]=nfree
     size_t *d_ucount = ar.lo<size_t>(4);          // unique counts
     HIP_OK(hipMemsetAsync(d_err, 0, sizeof(int32_t), s));
-    if (dim == 2) hipLaunchKernelGGL(k_sort_conn<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, out.conn, d_err);
-    else hipLaunchKernelGGL(k_sort_conn<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, out.conn, d_err);
+    if (g_element_order) {
+        out.eperm = ar.lo<int32_t>(nt);
+        const size_t mark = ar.hi_mark();
+        int32_t *conn_tmp = ar.hi<int32_t>(nt * nb), *ids = ar.hi<int32_t>(nt);
+        uint64_t *k_in = ar.hi<uint64_t>(nt), *k_out = ar.hi<uint64_t>(nt);
+        if (dim == 2) {
+            hipLaunchKernelGGL(k_sort_conn<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, conn_tmp, d_err);
+            hipLaunchKernelGGL(k_element_order_keys<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, conn_tmp, nbits, k_in, ids);
+        } else {
+            hipLaunchKernelGGL(k_sort_conn<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, conn_tmp, d_err);
+            hipLaunchKernelGGL(k_element_order_keys<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, conn_tmp, nbits, k_in, ids);
+        }
+        size_t tb = 0;
+        HIP_OK(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, ids, out.eperm, size_t(nt), 0u, unsigned(2 * nbits), s));
+        void *tmp = ar.hi<char>(tb + 256);
+        HIP_OK(rocprim::radix_sort_pairs(tmp, tb, k_in, k_out, ids, out.eperm, size_t(nt), 0u, unsigned(2 * nbits), s));
+        if (dim == 2) hipLaunchKernelGGL(k_gather_conn<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, conn_tmp, out.eperm, out.conn);
+        else hipLaunchKernelGGL(k_gather_conn<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, conn_tmp, out.eperm, out.conn);
+        ar.hi_release(mark);     // the stream orders the kernels that reuse this scratch behind the gather
+    } else {
+        if (dim == 2) hipLaunchKernelGGL(k_sort_conn<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, out.conn, d_err);
+        else hipLaunchKernelGGL(k_sort_conn<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, d_conn_in, out.conn, d_err);
+    }
 
     // ---- edges / faces: sort + unique ----------------------------------------------------------
     const size_t hi_mark0 = ar.hi_mark();
@@ -531,5 +577,6 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
 }
 
 void set_symbolic_tuning(int row_pattern) { g_row_pattern = row_pattern; }
+void set_element_order(int on) { g_element_order = on; }
 
 }  // namespace remo

@@ -507,13 +507,109 @@ def test_element_operator_is_ignored_in_2d(mesh2d, gpu_ctx):
         assert np.array_equal(u, v)
 
 
+def _rhs_block(k):
+    zs = np.linspace(-0.1, 0.1, k)
+    return [([float(z)], [1.0]) for z in zs], [[float(z) + 0.4, float(z) + 6.4] for z in zs]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 8])
+def test_patch_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
+    """remo_opts_t.op = 3 (3D): y = A x patch by patch (x rows staged in LDS, factorised reference tensors, LDS accumulation,
+    boundary slab) equals the CSR product and the oracle's; also with fewer columns than the batch was laid out for.  The sums
+    inside a patch are unordered: agreement to rounding, not bit for bit."""
+    from remo3d_amd import solver
+    from oracle.fem_oracle import Oracle
+    o = Oracle(mesh3d, SIGMA3, condense=True)
+    src, ev = _rhs_block(k)
+    b = gpu_ctx.batch(mesh3d, SIGMA3, src, ev)
+    try:
+        ys = {}
+        for kk in sorted({k, max(1, k - 1), 1}):
+            x = np.random.default_rng(10 * k + kk).standard_normal((o.nfree, kk))
+            xx = x if kk > 1 else x[:, 0]
+            for op in ("csr", "patch"):
+                b.run(solver.make_opts(preconditioner="local", rtol=1e-2, op=op))
+                assert b.stats["op_used"] == (3 if op == "patch" else 0)
+                ys[op], _ = b.spmv(xx, reps=2)
+            yr = np.stack([o.spmv(x[:, c]) for c in range(kk)], 1).reshape(ys["csr"].shape)
+            scale = np.max(np.abs(yr))
+            assert np.max(np.abs(ys["patch"] - yr)) <= 5e-12 * scale, (k, kk)
+            assert np.max(np.abs(ys["patch"] - ys["csr"])) <= 5e-12 * scale, (k, kk)
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+@pytest.mark.parametrize("pre", ["local", "multigrid"])
+def test_patch_operator_solves_like_the_csr_path(precision, pre, mesh3d, gpu_ctx):
+    """The same PCG on the patch operator: potentials of the CSR path and of the oracle, similar step counts, the TRUE residual
+    of the returned solution; 9 right-hand sides (chunks of 8 + 1: the single column runs through tables laid out for 8)."""
+    from remo3d_amd import solver
+    o, ref = _oracle_solve(mesh3d, SIGMA3, True)
+    res = {}
+    for op in ("csr", "patch"):
+        outs, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-12, maxsteps=20000, precision=precision, op=op))
+        assert rc == 0 and st["op_used"] == (3 if op == "patch" else 0)
+        res[op] = (outs, max(st["iterations"][:3]))
+        for g, r in zip(outs, ref):
+            assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
+    assert abs(res["csr"][1] - res["patch"][1]) <= max(3, res["csr"][1] // 20), (res["csr"][1], res["patch"][1])
+    zs = np.linspace(-0.4, 0.4, 9)
+    src = [([z], [1.0]) for z in zs]
+    ev = [[z + 0.4, z + 6.4] for z in zs]
+    a, _, rca = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="patch", maxsteps=5000))
+    c, _, rcc = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="csr", maxsteps=5000))
+    assert rca == 0 and rcc == 0
+    for u, v in zip(a, c):
+        assert np.allclose(u, v, rtol=1e-8, atol=0)
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        assert b.run(solver.make_opts(preconditioner=pre, rtol=1e-11, maxsteps=5000, precision=precision, op="patch")) == 0
+        assert np.max(b.true_relres()) < 5e-11
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
+def test_patch_operator_without_element_locality(mesh3d, gpu_ctx):
+    """The library orders the elements itself (by their smallest vertices): a mesh handed over with shuffled elements gives
+    the same potentials through the patch operator, and so does the shuffled list taken as it comes (remo_debug_tune 18 = 0:
+    patches of unrelated elements hold up to 20 distinct rows per element - slower, not wrong)."""
+    import copy
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    ref, _, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-11, op="csr"))
+    assert rc == 0
+    perm = np.random.default_rng(3).permutation(mesh3d.n_elems)
+    sh = copy.copy(mesh3d)
+    sh.conn = np.ascontiguousarray(mesh3d.conn[perm]); sh.mat = np.ascontiguousarray(mesh3d.mat[perm])
+    for order in (1, 0):
+        L.remo_debug_tune(18, order)
+        try:
+            outs, st, rc = gpu_ctx.solve_batch(sh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-11, op="patch"))
+        finally:
+            L.remo_debug_tune(18, 1)
+        assert rc == 0 and st["op_used"] == 3
+        for u, v in zip(outs, ref):
+            assert np.allclose(u, v, rtol=1e-8, atol=0)
+
+
 @pytest.mark.gpu
 def test_operator_choice_by_size(mesh3d, gpu_ctx):
     """op = "auto" (the default): CSR product while the matrix stays in the Infinity Cache (17 M stored entries), element-wise above;
     the statistics say which one ran."""
     from remo3d_amd import solver
+    from remo3d_amd import _lib
     _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6))
-    assert rc == 0 and st["nnz"] < 17000000 and st["op_used"] == 0
+    assert rc == 0 and st["op_used"] == 3          # round 3: the patch operator wherever its tables fit
+    _lib.load().remo_debug_tune(20, 0)              # the round-2 rule: by stored entries
+    try:
+        _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6))
+        assert rc == 0 and st["nnz"] < 17000000 and st["op_used"] == 0
+    finally:
+        _lib.load().remo_debug_tune(20, 1)
     _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, op="element"))
     assert rc == 0 and st["op_used"] == 1
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Operator application (k = 5) and whole solves through the three operators on bench meshes:
+   python tools/probe_patch.py S M L      (CSR product | element-wise | patch, two / one column per lane)"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--ops="):
+            only = a[6:].split(",")
+    sizes = args or ["S"]
+    work = {}
+    for sz in sizes:
+        t0 = time.time()
+        wl = bench.build_workload(0, 1, 20, bench.SIZES[sz], max_batches=1)
+        work[sz] = wl["work"][0]
+        print("mesh %s: T=%d built in %.1f s" % (sz, work[sz]["mesh"].n_elems, time.time() - t0), flush=True)
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    out = []
+    with solver.Context(0) as ctx:
+        for sz in sizes:
+            w = work[sz]
+            b = ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"])
+            ref = None
+            for name, op, cpl, mode in (("csr", "csr", 1, 0), ("element", "element", 1, 0), ("patch", "patch", 1, 0),
+                                        ("patch/no-atomics", "patch", 1, 1), ("patch/no-arithmetic", "patch", 1, 2), ("patch/no-output", "patch", 1, 3)):
+                if only and name not in only:
+                    continue
+                if mode and not only:
+                    continue
+                L.remo_debug_tune(21, 0)
+                rc = b.run(solver.make_opts(rtol=1e-8, op=op), raise_on_error=False)
+                st = dict(b.stats)
+                n = st["n_free"]
+                x = np.random.default_rng(0).standard_normal((n, 5))
+                L.remo_debug_tune(21, mode)
+                y, ms = b.spmv(x, reps=30)
+                L.remo_debug_tune(21, 0)
+                if ref is None:
+                    ref = y
+                err = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+                u = np.concatenate(b.fetch())
+                rec = dict(size=sz, op=name, rc=rc, op_used=st["op_used"], T=int(w["mesh"].n_elems), n=n, nnz=st["nnz"], apply_us=1e3 * ms, rel_diff_vs_csr=err,
+                           pcg_steps=st["pcg_steps"], solve_ms=st["ms_solve"], symbolic_ms=st["ms_symbolic"], assemble_ms=st["ms_assemble"], total_ms=st["ms_total"],
+                           u0=float(u[0]))
+                out.append(rec)
+                print(json.dumps(rec), flush=True)
+            b.close()
+    return out
+
+if __name__ == "__main__":
+    main()

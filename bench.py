@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 SIZES = {"S": 4.0, "M": 2.5, "L": 1.2, "XL": 0.7}   # multiplier on the reference size field
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TOOLS = ["A0.4M6.0N", "A2.0M0.5N"]
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic_default_bench.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic_default_bench.json")
 
 
 def _model_and_batches(n_depths):
@@ -135,45 +135,67 @@ def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice",
     return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=list(TOOLS))
 
 
-def cpu_baseline(work, rtol, cores=None):
-    """The oracle (scalar C port of the same algorithm) the way the reference farms its work out
-    (remo3d.py:592-595, worker.py:104-112: one single-threaded worker per core, every right-hand side
-    assembled and solved on its own): `cores` host threads, each running assembly + Jacobi-PCG +
-    evaluation of ONE right-hand side of the workload at the same time (the C calls release the GIL).
-    Reported beside the GPU number, never the target.  Returns (record, potentials of batch 0 / RHS 0)."""
-    from concurrent.futures import ThreadPoolExecutor
+def _cpu_leg_main(path):
+    """Child process of the CPU leg: ONE right-hand side of the workload (batch 0, RHS 0) through oracle/fem_oracle.c - assembly,
+    Jacobi-PCG to the same rtol, evaluation - on one host core, run to completion; result as JSON next to the input."""
+    import pickle
+    import numpy as np   # noqa: F401
+    with open(path, "rb") as f:
+        job = pickle.load(f)
     from oracle.fem_oracle import lib, solve_batch
     lib()                                            # compile / load outside the timed span
-    if cores is None:
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        cores = max(1, min(avail, 16))
-    jobs = []
-    for bi, w in enumerate(work):
-        for ri in range(len(w["sources"])):
-            jobs.append((bi, ri))
-    jobs = jobs[:cores]
-
-    def one(job):
-        w = work[job[0]]
-        z, I = w["sources"][job[1]]
-        ez = list(w["evals"][job[1]])
-        out, rc, st = solve_batch(w["mesh"], w["sigma"], [0, len(z)], list(z), list(I), [0, len(ez)], ez, condense=True, rtol=rtol, maxit=1000)
-        return out, st["iterations"]
-
+    z, I = job["source"]
+    ez = list(job["evals"])
     t0 = time.time()
-    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
-        res = list(ex.map(one, jobs))
+    out, rc, st = solve_batch(job["mesh"], job["sigma"], [0, len(z)], list(z), list(I), [0, len(ez)], ez, condense=True, rtol=job["rtol"], maxit=job["maxit"])
     dt = time.time() - t0
-    pts = sum(len(work[bi]["readers"][ri]) for bi, ri in jobs)
-    its = [r[1] for r in res]
-    return dict(value=pts / dt, unit="points/s", cores=len(jobs), kind="port",
-                sample=f"the first {len(jobs)} right-hand sides of the workload ({pts} points), one per host thread at the same time, "
-                       f"each its own oracle/fem_oracle.c assembly + Jacobi-PCG (rtol {rtol:g}, {min(its)}-{max(its)} steps) + evaluation: "
-                       f"{dt:.1f} s wall; NGSolve is not installable here, so this is the build's scalar C restatement run one worker per "
-                       "core like the reference's farm, not the reference binary"), res[0][0]
+    with open(path + ".json", "w") as f:
+        json.dump(dict(seconds=dt, rc=int(rc), iterations=st["iterations"], n=st.get("n"), out=[float(v) for v in out]), f)
+
+
+def cpu_baseline_start(work, rtol, maxit):
+    """The oracle (scalar C port of the same algorithm) the way ONE worker of the reference's farm runs (remo3d.py:592-595,
+    worker.py:104-112: a single-threaded process that assembles and solves a right-hand side on its own): started as a child
+    process on one host core right after the meshes exist, so that its minutes of CPU time pass beside the GPU legs instead of
+    behind them (at the reference's resolution one right-hand side is ~2 M unknowns and 750 Jacobi-PCG steps: 1.5-3 minutes of
+    one core - the smallest complete sample there is).  Reported beside the GPU number, never the target."""
+    import pickle
+    import tempfile
+    w = work[0]
+    fd, path = tempfile.mkstemp(prefix="remo_cpu_leg_", suffix=".pkl")
+    with os.fdopen(fd, "wb") as f:
+        pickle.dump(dict(mesh=w["mesh"], sigma=w["sigma"], source=w["sources"][0], evals=w["evals"][0], rtol=rtol, maxit=maxit), f)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-leg", path], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return dict(proc=proc, path=path, points=len(w["readers"][0]), t0=time.time())
+
+
+def cpu_baseline_finish(leg, timeout_s=600.0):
+    """Wait for the child of cpu_baseline_start.  Returns (record, potentials of batch 0 / RHS 0) or (record with an error, None)."""
+    proc, path = leg["proc"], leg["path"]
+    try:
+        proc.wait(timeout=max(1.0, timeout_s))
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        return dict(value=None, unit="points/s", cores=1, kind="port", sample="the CPU leg did not finish within %.0f s" % timeout_s), None
+    try:
+        with open(path + ".json") as f:
+            r = json.load(f)
+    except OSError:
+        return dict(value=None, unit="points/s", cores=1, kind="port", sample="the CPU leg failed: " + proc.stderr.read().decode()[-300:]), None
+    finally:
+        for q in (path, path + ".json"):
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+    import numpy as np
+    pts = leg["points"]
+    return dict(value=pts / r["seconds"], unit="points/s", cores=1, kind="port", seconds=r["seconds"], pcg_iterations=r["iterations"],
+                sample=f"ONE right-hand side of the workload (batch 0, RHS 0: {pts} point(s), {r.get('n')} unknowns) on ONE host core, run to completion beside the GPU legs: "
+                       f"oracle/fem_oracle.c assembly + Jacobi-PCG (rtol as the GPU run, {r['iterations']} steps, rc {r['rc']}) + evaluation in {r['seconds']:.1f} s.  "
+                       "The reference farms such workers out one per core (remo3d.py:592-595); NGSolve is not installable here, so this is the build's "
+                       "scalar C restatement, not the reference binary"), np.asarray(r["out"])
 
 
 def box_stream(device):
@@ -209,15 +231,15 @@ def box_stream(device):
         return dict(error="%s: %s" % (type(ex).__name__, ex))
 
 
-def pmc_traffic(workload, n_free, nnz):
-    """HBM bytes per SpMM launch from the committed rocprofv3 --pmc passes of this exact workload
+def pmc_traffic(workload, n_free, nnz, op="csr"):
+    """HBM bytes per operator application from the committed rocprofv3 --pmc passes of this exact workload
     (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             p = json.load(f)
     except OSError:
         return None
-    if p.get("workload") == workload and p.get("n_free") == n_free and p.get("nnz") == nnz:
+    if p.get("workload") == workload and p.get("n_free") == n_free and p.get("nnz") == nnz and p.get("operator", "csr") == op:
         return p["spmm"]["traffic_bytes_per_launch"]
     return None
 
@@ -337,20 +359,30 @@ def timed(runner, steps, warmup, sync, **kw):
 
 
 def roofline_of(agg, precision, stride, workload_name=None):
+    """The operator application of the CG (what `time_kernels` brackets: every launch of it) against the HBM roofline, priced by
+    ITS OWN algorithmic bytes (remo_stats_t.spmv_bytes): CSR product 12 nnz + 4 n + 16 k n; patch operator 16 k n + 88 T (x read and
+    y written once, 40 bytes of local indices + 48 of metric terms per element - no stored entries)."""
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
+    op = {0: "csr", 1: "element", 3: "patch"}.get(int(agg.get("op_used", 0)), "csr")
     r = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
-             traffic=pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"])) if (workload_name and precision == "fp64") else None)
-    elem = bool(agg.get("op_used"))
-    r.update(kernel=("k_elem_apply + k_elem_reduce (element-wise operator, %s; `achieved` prices the CSR product's algorithmic bytes at this time)" if elem
-                     else "k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)") % ("fp64" if precision == "fp64" else "fp32 values and vectors"),
-             operator="element" if elem else "csr",
-             timed="every %d-th launch of every solve, HIP events on the solver's stream, over the timed steps" % stride,
+             traffic=pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"]), op) if (workload_name and precision == "fp64") else None)
+    prec = "fp64" if precision == "fp64" else "fp32 values and vectors"
+    kernel = {"csr": "k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)",
+              "element": "k_elem_apply + k_elem_reduce (element-wise operator with a slab of element results, %s; `achieved` prices the CSR product's bytes)",
+              "patch": "k_patch_apply + k_patch_reduce (matrix-free patch operator, %s, k=5 interleaved RHS; both launches inside the bracket)"}[op] % prec
+    fp = precision == "fp64"
+    formula = {"csr": "12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if fp else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)",
+               "element": "12*nnz + 4*n + 16*k*n (the CSR product's figure)" if fp else "8*nnz + 4*n + 8*k*n",
+               "patch": "16*k*n + 88*T (x and y once, 40 B local indices + 48 B metric terms per element)" if fp else "8*k*n + 88*T"}[op]
+    r.update(kernel=kernel, operator=op,
+             timed="every %d-th application of every solve, HIP events on the solver's stream, over the timed steps" % stride,
              launches=int(agg["spmv_launches"]),
              avg_launch_us=(1e3 * agg["spmv_ms"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
              avg_bracket_us_raw=(1e3 * agg["spmv_ms_raw"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
              empty_event_pair_us=1e3 * agg["ev_over"],
-             bytes_per_launch="12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if precision == "fp64" else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)",
-             traffic_unit="bytes per launch: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE, " + PMC_FILE)
+             bytes_per_launch=formula,
+             algorithmic_bytes_per_launch=(agg["spmv_bytes_total"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
+             traffic_unit="bytes per application: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE over the kernels of the bracket, " + PMC_FILE)
     return r
 
 
@@ -365,11 +397,15 @@ T_START = time.time()
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-leg":
+        return _cpu_leg_main(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", default="S", choices=list(SIZES))
+    ap.add_argument("--size", default="L", choices=list(SIZES),
+                    help="multiplier class of the reference size field: L = 1.2 x (the reference's resolution, ~2 M dofs per batch: the headline), "
+                         "S = 4 x coarser (the round-1/2 headline), M, XL (BASELINE config 5's ~5 M dofs)")
     ap.add_argument("--depths", type=int, default=100, help="measurement depths per GPU (weak scaling)")
     ap.add_argument("--total-depths", type=int, default=0,
                     help="strong scaling: this many depths in all, shared by the ranks (BASELINE configs[3]: 1000)")
@@ -383,10 +419,10 @@ def main():
                          "conforming revolved meshes Model uses by default for dipping models")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="fp64 (the headline configuration) or mixed = fp32 PCG inside fp64 refinement (BASELINE config 5)")
-    ap.add_argument("--op", default="auto", choices=["auto", "csr", "element"],
+    ap.add_argument("--op", default="auto", choices=["auto", "csr", "element", "patch"],
                     help="how the CG applies A: csr = SpMM on the assembled matrix; element = element-wise operator through the factorised "
-                         "reference tensors; auto (the library's default) = csr up to 17 M stored entries - the headline size S, whose SpMM the "
-                         "roofline object describes - element-wise above")
+                         "reference tensors (slab of element results); patch = the same tensors patch by patch with LDS-staged vectors (round 3); "
+                         "auto (the library's default) = patch in 3D")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
                          "1 = the headline configuration (per-launch SpMM timing is only meaningful without overlap)")
@@ -394,12 +430,12 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="M:8,M/csr:8,L:4,L/csr:4,L/mixed:4,conforming-M:8,2D-BM1:8,2D-BM1/chebyshev:8,2D-BM1/2ctx:8,2D-BM1/mixed:8",
+    ap.add_argument("--sizes", default="L/csr:4,L/mixed:4,S:8,S/csr:8,M:8,XL:2,XL/mixed:2,conforming-M:8,2D-BM1:8,2D-BM1/2ctx:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
                          "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size; '2D-BM1' = BASELINE configs[1], "
                          "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block, '/2ctx' = two contexts (streams, host threads) share the batches), reported in the `sizes` array; '' = none")
     ap.add_argument("--no-extras", action="store_true", help="skip the `sizes` and H2D-inclusive legs")
-    ap.add_argument("--mesh-workers", type=int, default=6, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
+    ap.add_argument("--mesh-workers", type=int, default=10, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B experiments only: remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip_debug.h lists the keys)")
@@ -458,6 +494,9 @@ def main():
     mesh_wall = time.time() - t_mesh0
     log("meshes built: %d batches of the headline workload + %s in %.1f s" % (len(wl["work"]), [(n, len(w["work"])) for n, w in extra_wl], mesh_wall))
 
+    cpu_leg = None
+    if not args.no_cpu and world == 1 and not profiled:           # the CPU leg belongs to the N = 1 line only; it runs beside the GPU legs
+        cpu_leg = cpu_baseline_start(wl["work"], args.rtol, 20000)
     from remo3d_amd import solver, sweep
     if args.tune:
         from remo3d_amd import _lib
@@ -508,7 +547,7 @@ def main():
                config=dict(workload=workload_name, schedule=args.schedule if world > 1 else "single rank",
                            batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
                            points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
-                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator="element" if agg["op_used"] else "csr",
+                           maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator={0: "csr", 1: "element", 3: "patch"}.get(int(agg["op_used"]), "csr"),
                            preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
                            max_pcg_iterations=int(agg["max_it"]), batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline_of(agg, args.precision, stride, workload_name),
@@ -544,14 +583,7 @@ def main():
         out["value_h2d_inclusive"] = dict(value=n_points * max(1, min(args.steps, 2)) / dth, unit="points/s",
                                           note="remo_solve_batch per batch: upload of the mesh arrays (pageable host memory) + run + fetch inside the timed span",
                                           max_abs_log_diff_vs_resident=float(np.nanmax(np.abs(slab_h - slab))))
-    if not args.no_cpu and world == 1:           # the CPU leg belongs to the N = 1 line only
-        cb, ref_out = cpu_baseline(work, args.rtol)
-        log("CPU baseline leg done")
-        out["cpu_baseline"] = cb
-        got = runner.resident[0].fetch()[0]
-        out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got - ref_out) / np.abs(ref_out)))
-    else:
-        out["cpu_baseline"] = None
+    got0 = runner.resident[0].fetch()[0].copy()
     runner.close()
     if extras:
         out["box"] = box_stream(local)
@@ -559,7 +591,7 @@ def main():
     sizes = []
     for name, w2 in extra_wl:
         prec2 = "mixed" if "/mixed" in name else args.precision
-        op2 = "element" if "/element" in name else ("csr" if "/csr" in name else args.op)
+        op2 = "element" if "/element" in name else ("csr" if "/csr" in name else ("patch" if "/patch" in name else args.op))
         coarse2 = "chebyshev" if "/chebyshev" in name else "auto"
         opts2 = solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
                                  time_kernels=0 if args.no_events else stride, precision=prec2, op=op2, coarse=coarse2)
@@ -568,15 +600,22 @@ def main():
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)
         pts = sum(len(rd) for w in w2["work"] for rd in w["readers"])
         rf = roofline_of(agg2, prec2, stride)
-        op2 = "element" if agg2["op_used"] else "csr"
+        op2 = {0: "csr", 1: "element", 3: "patch"}.get(int(agg2["op_used"]), "csr")
         sizes.append(dict(workload=name, precision=prec2, operator=op2, vertex_block_solver={0: "none", 1: "chebyshev", 2: "multigrid cycle"}[agg2.get("coarse_used", 1)], contexts=2 if "/2ctx" in name else 1, batches=len(w2["work"]), points=pts, value=pts * st2 / dt2, unit="points/s", mesh_T=int(w2["work"][0]["mesh"].n_elems),
                           n_free=int(agg2["n"]), nnz=int(agg2["nnz"]), pcg_steps_per_batch=agg2["pcg_steps"] / max(1, agg2["batches"]),
-                          max_pcg_iterations=int(agg2["max_it"]), spmm_frac=rf["frac"] if op2 == "csr" else None, apply_avg_launch_us=rf["avg_launch_us"],
+                          max_pcg_iterations=int(agg2["max_it"]), operator_frac_of_hbm_peak=rf["frac"], operator_bytes=rf["bytes_per_launch"], apply_avg_launch_us=rf["avg_launch_us"],
                           solve_ms_per_batch=agg2["ms_solve"] / max(1, agg2["batches"]), nan_points=int(np.isnan(slab2).sum())))
         r2.close()
         log("size leg %s done: %.3f s for %d steps" % (name, dt2, st2))
     if extras:
         out["sizes"] = sizes
+    out["cpu_baseline"] = None
+    if cpu_leg is not None:
+        cb, ref_out = cpu_baseline_finish(cpu_leg)
+        log("CPU baseline leg done")
+        out["cpu_baseline"] = cb
+        if ref_out is not None:
+            out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got0 - ref_out) / np.abs(ref_out)))
     print(json.dumps(out))
 
 

@@ -90,7 +90,9 @@ typedef struct {
                                    the polynomial of degree 28 at a quarter of its launches), the polynomial in 3D (there it is
                                    within 15 % of an exact vertex solve at degree 5-13 and the cycle gains nothing).
                                If the hierarchy cannot be built (a vertex of extreme valence) 0 falls back to the polynomial, 2 fails */
-    int32_t reserved_opts;
+    int32_t quadrature;     /* 2D: how the reference tensors of `2 pi x sigma grad(u) grad(v)` (ngsolve_functions.py:34; a degree-5 integrand) are
+                               integrated: 0 = exactly (default); 1 = by the 6-point rule that is exact to degree 4 - the alternative NGSolve
+                               may be using (its rule order is not pinned by the reference).  3D integrands have degree 4: always exact */
 } remo_opts_t;
 
 typedef struct {

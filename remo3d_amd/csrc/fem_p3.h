@@ -155,7 +155,8 @@ template <int DIM> REMO_HD bool barycentrics(const double *X, const double *P, d
 }
 
 // host: exact reference tensors (ref_tables.cpp)
-const double *ref_tables(int dim);  // [NTERM][NLD][NLD]
+const double *ref_tables(int dim);  // [NTERM][NLD][NLD], exact integrals
+const double *ref_tables2_rule4();   // 2D tensors by the 6-point degree-4 rule instead (remo_opts_t.quadrature = 1)
 const double *ref_factors3();        // [3][10][20]: B[a][m][i], mean_T(D_a phi_i D_b phi_j) = sum_m B[a][m][i] B[b][m][j]
 double ref_factors3_error();         // max deviation of the factorised form from ref_tables(3)
 

@@ -124,6 +124,7 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
 
 template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step);   // patch.hip
 void set_patch_mode(int mode);
+void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps
 int patch_elements_per_group(int kmax);
 
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0

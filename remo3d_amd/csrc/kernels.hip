@@ -481,6 +481,7 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
 // What it buys: the CSR product gathers an x row once per STORED ENTRY (54 times per edge row pair), this one once per
 // incident ELEMENT (6.3 M lane-requests instead of 42 M at 63 k tetrahedra), and it reads 128 bytes per element instead
 // of 2.6 kB of matrix: the work moves from the vector-memory path, which bounds the CSR kernel, to the fp64 pipes.
+#define REMO_ELEM_NS elem_tables_kernels
 #include "build/elem_apply.inc"
 
 // slot[t * 20 + li] = position of (element t, local dof li) in the row-sorted adjacency list, -1 for constrained dofs: where
@@ -543,7 +544,7 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
             buf_load<T, 2>(rx, ed[i] >= 0 ? (uint32_t(ed[i]) * K + c0) * S : kOutOfRange, w);
             xv[i].x = w[0]; xv[i].y = two ? w[1] : T(0);
         }
-        REMO_ELEM_GRAD(T2, xv, g)
+        REMO_ELEM_GRAD(T2, xv, g, ElemTables<T>::grad())
 #pragma unroll
         for (int m = 0; m < 10; ++m) {     // h = c~ g, in place
             const T2 g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
@@ -551,7 +552,7 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
             g[10 + m] = c12 * g1 + c22 * g2 + c23 * g3;
             g[20 + m] = c13 * g1 + c23 * g2 + c33 * g3;
         }
-        REMO_ELEM_DIV(T2, g, y)
+        REMO_ELEM_DIV(T2, g, y, ElemTables<T>::div())
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const uint32_t off = sl[i] >= 0 ? (uint32_t(sl[i]) * K + c0) * S : kOutOfRange;
@@ -710,7 +711,7 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
     // patch operator (patch.hip): its tables are laid out for the batch's own column count - a product with more columns than
     // that (inspection hooks only) goes through the stored matrix
-    if (A.patch && k * A.patch->t.E <= 256 && size_t(A.patch->lds_rows + 2) * k * sizeof(T) <= 60 * 1024) {
+    if (A.patch && k * A.patch->t.E <= 256 && size_t(A.patch->lds_rows + 2) * k * sizeof(T) + size_t(A.patch->lds_rows + 12 * (256 / k)) * 8 <= 60 * 1024) {
         launch_patch_spmm(A, k, x, y, part, scal, nb, s, step);
         return;
     }

@@ -26,12 +26,14 @@
 #include "symbolic_gpu.h"
 #include "wave_util.h"
 
+#define REMO_ELEM_NS elem_tables_patch
 #include "build/elem_apply.inc"
 
 namespace remo {
 
 namespace {
 
+constexpr int kPatchPasses = 12;                       // k_patch_apply: loads a lane keeps in flight
 constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192
 constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
 
@@ -133,6 +135,14 @@ __global__ void __launch_bounds__(256) k_patch_build(int64_t nt, int E, int rows
     }
 }
 
+// Constrained dofs read (and add into) a row of zeros behind the staged rows: local row = the largest row count of any patch,
+// known once every patch is built (device-side value: no host round trip) - so the kernel needs no test per dof.
+__global__ void __launch_bounds__(256) k_patch_zero_rows(int64_t nslots, uint16_t *__restrict__ lidx, const int32_t *__restrict__ max_rows) {
+    const uint16_t z = uint16_t(max_rows[0] < 0xFFFF ? max_rows[0] : 0xFFFE);
+    for (int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; j < nslots; j += int64_t(gridDim.x) * blockDim.x)
+        if (lidx[j] == 0xFFFF) lidx[j] = z;
+}
+
 // Slab slots.  The slab is PATCH-major: the shared rows of patch p own the slots pboff[p], pboff[p] + 1, ... in ascending row order,
 // so a patch writes one contiguous block, and the rows of a block read by k_patch_reduce are neighbours too.  One workgroup per
 // patch: pout[p][m] = slot of local row m (-1 stays: not shared), and the row's list bslot[bptr[row] + rank of this patch among the
@@ -183,12 +193,20 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
 // atomics, 2 = no tensor arithmetic (y = x), 3 = nothing leaves the workgroup.
 template <class T, int K, int MODE = 0>
 __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
-                                                     double *__restrict__ ppart, const double *__restrict__ scal, int step) {
+                                                     double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps) {
     if (scal && solve_done(scal, step)) return;
+    // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
+#define REMO_STAMP(k) if constexpr (MODE == 4) { if (threadIdx.x == 0) stamps[(int64_t(blockIdx.x) << 3) + (k)] = __builtin_readcyclecounter(); }
+    REMO_STAMP(0)
     constexpr int NL = K;
-    constexpr int U = 4;                                 // independent loads in flight per lane and trip
+    constexpr int U = kPatchPasses;                      // loads in flight per lane: one trip over up to U * (256 / K) rows
+    constexpr int EK = 256 / K;                          // rows per pass of the staging / output phases
+    constexpr uint32_t S = sizeof(T);
+    const int rows_pad = (rows + U * EK - 1) / (U * EK) * (U * EK);
     extern __shared__ double lds_raw[];
-    T *xs = reinterpret_cast<T *>(lds_raw);              // [(rows + 2)][K]: x rows, later the accumulators of y; row `rows` = zeros
+    T *xs = reinterpret_cast<T *>(lds_raw);              // [(rows + 2)][K]: x rows, later the accumulators of y; row `rows` = zeros, row rows + 1 = slack
+    int32_t *trow = reinterpret_cast<int32_t *>(lds_raw + ((size_t(rows + 2) * K * sizeof(T) + 7) >> 3));   // [rows_pad] matrix row of local row m
+    int32_t *tout = trow + rows_pad;                     // [rows_pad] -1 or slab slot
     __shared__ double smem[16 * K];
     const int tid = threadIdx.x;
     // workgroups b, b + 8, ... share an XCD and its L2: every XCD takes one contiguous eighth of the patches (neighbouring patches
@@ -198,12 +216,13 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
     if (p >= tb.npatch) return;
     const int32_t *prow = tb.prow + p * tb.rows_cap, *pout = tb.pout + p * tb.rows_cap;
     const int el = tid / NL, c0 = tid - el * NL;
+    const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);   // or-ed into a row number: negative = no row for this lane
     const int64_t e = p * tb.E + el;
     const bool active = el < tb.E && e < tb.nt;
     uint32_t li[10];
     double cm[6];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) li[q] = 0xFFFFFFFFu;
+    for (int q = 0; q < 10; ++q) li[q] = 0u;
 #pragma unroll
     for (int q = 0; q < 6; ++q) cm[q] = 0.0;
     if (active) {
@@ -214,46 +233,61 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
 #pragma unroll
         for (int q = 0; q < 6; ++q) cm[q] = ce[q];
     }
-    // 1. stage the patch's x rows, ONE VALUE per lane and pass: lane j takes value j of the staged image, so neighbouring lanes
-    // read neighbouring addresses inside a row and across consecutive rows (a patch's rows come in a few runs of consecutive
-    // matrix rows) - a wave's load covers a handful of cache lines.  (A k-wide row per lane spreads every load instruction of a
-    // wave over 20-40 lines, three instructions per row: that, not the arithmetic, was the kernel time.)  prow holds -1 behind a
-    // patch's last row, so no row count has to arrive first.  Row `rows` is the zero row constrained dofs read (and add into).
-    const int nw = rows * K;
-    for (int j0 = tid; j0 < nw; j0 += U * 256) {
+    // 1a. the patch's row tables into LDS (one round trip; the output phase finds them there again).  prow holds -1 behind a
+    // patch's last row, so no row count has to arrive first; the LDS copies are padded with -1 to whole passes of 1b.
+    for (int m0 = tid; m0 < rows_pad; m0 += 4 * 256) {
+        int32_t r[4], o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + 256 * u;
+            r[u] = m < rows ? prow[m] : -1;
+            o[u] = m < rows ? pout[m] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + 256 * u;
+            if (m < rows_pad) { trow[m] = r[u]; tout[m] = o[u]; }
+        }
+    }
+    __syncthreads();
+    REMO_STAMP(1)
+    // 1b. stage the patch's x rows, ONE VALUE per lane and load: in pass u lane (el, c0) takes column c0 of local row el + EK u
+    // (EK = 256 / K rows per pass), i.e. value tid + EK K u of the staged image - neighbouring lanes read neighbouring addresses
+    // inside a row and across consecutive rows (a patch's rows come in a few runs of consecutive matrix rows), no division per
+    // value, and ALL loads of a lane are in flight together (U passes; the phase is one memory round trip, not one per pass: a
+    // round trip is ~2-5 k clocks here, the arithmetic of a whole patch ~4 k).  Buffer loads with the hardware range check: a lane
+    // without a row hands over an offset beyond the descriptor (no request, no branch); its LDS store goes to the slack row.
+    // 24-bit multiplies: rows and slots are below 2^24 (checked by the caller).  Row `rows` is the zero row constrained dofs read.
+    const rsrc_t rx = make_rsrc(x, uint64_t(tb.n) * K * S);
+    const uint32_t slack = uint32_t((rows + 1) * K + c0);
+    for (int m0 = 0; m0 < rows; m0 += U * EK) {
         int32_t r[U];
-        T v[U];
+        T v[U][1];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 256 * u;
-            r[u] = j < nw ? prow[j / K] : -1;
-        }
+        for (int u = 0; u < U; ++u) r[u] = trow[m0 + el + EK * u] | off_mask;     // lanes beyond the last whole row of a pass: no row
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 256 * u;
-            v[u] = r[u] >= 0 ? x[int64_t(r[u]) * K + (j % K)] : T(0);
-        }
+        for (int u = 0; u < U; ++u)
+            buf_load<T, 1>(rx, r[u] >= 0 ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 256 * u;
-            if (j < nw) xs[j] = v[u];
-        }
+        for (int u = 0; u < U; ++u) xs[r[u] >= 0 ? uint32_t((m0 + el + EK * u) * K + c0) : slack] = v[u][0];
     }
     if (tid < 2 * K) xs[rows * K + tid] = T(0);
     __syncthreads();
+    REMO_STAMP(2)
     // 2. my element, my column
     T xv[20];
     if (active) {
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-            uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            l = l == 0xFFFFu ? uint32_t(rows) : l;
+            const uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;      // constrained dofs: the zero row (k_patch_zero_rows)
             xv[i] = xs[l * K + c0];
         }
     }
     __syncthreads();        // every lane holds its x values: the staging area becomes the accumulators
+    REMO_STAMP(3)
     for (int j = tid; j < (rows + 1) * K; j += 256) xs[j] = T(0);
     __syncthreads();
+    REMO_STAMP(4)
     double d0 = 0.0;
     if (active) {
         const T c11 = T(cm[0]), c12 = T(cm[1]), c13 = T(cm[2]), c22 = T(cm[3]), c23 = T(cm[4]), c33 = T(cm[5]);
@@ -262,7 +296,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
 #pragma unroll
             for (int i = 0; i < 20; ++i) yv[i] = xv[i] * c11;
         } else {
-            REMO_ELEM_GRAD(T, xv, g)
+            REMO_ELEM_GRAD(T, xv, g, ElemTables<T>::grad())
             T dd = T(0);
 #pragma unroll
             for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
@@ -272,7 +306,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
                 g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
             }
             d0 = double(dd);
-            REMO_ELEM_DIV(T, g, yv)
+            REMO_ELEM_DIV(T, g, yv, ElemTables<T>::div())
         }
         // the local rows are read a second time for the accumulation (an L1 / L2 hit) instead of being held in ten registers
         // through the tensor arithmetic: that is the difference between three and four waves per SIMD in fp64
@@ -283,33 +317,34 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
         }
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-            uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            l = l == 0xFFFFu ? uint32_t(rows) : l;
+            const uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
             if constexpr (MODE == 1) xs[l * K + c0] = yv[i];
             else lds_add(xs + l * K + c0, yv[i]);
         }
     }
     __syncthreads();
+    REMO_STAMP(5)
     // 3. rows of this patch alone -> y; shared rows -> the patch's block of the boundary slab; one value per lane and pass again
     if constexpr (MODE != 3) {
-        for (int j0 = tid; j0 < nw; j0 += U * 256) {
+        const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
+        for (int m0 = 0; m0 < rows; m0 += U * EK) {
             int32_t r[U], o[U];
+            T v[U][1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + 256 * u;
-                r[u] = j < nw ? prow[j / K] : -1;
-                o[u] = j < nw ? pout[j / K] : -1;
+                const int m = m0 + el + EK * u;
+                r[u] = trow[m] | off_mask; o[u] = tout[m];
+                v[u][0] = xs[m * K + c0];       // (behind the staged rows: whatever LDS holds, never stored)
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = j0 + 256 * u;
-                if (r[u] >= 0) {
-                    T *dst = o[u] < 0 ? y + int64_t(r[u]) * K : Yb + int64_t(o[u]) * K;
-                    dst[j % K] = xs[j];
-                }
+            for (int u = 0; u < U; ++u) {       // one of the two stores of a value is out of range: dropped by the hardware, no branch
+                const bool have = r[u] >= 0;
+                buf_store<T, 1>(ry, (have && o[u] < 0) ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                buf_store<T, 1>(rb, (have && o[u] >= 0) ? __umul24(uint32_t(o[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
             }
         }
     }
+    REMO_STAMP(6)
     if (ppart) {
         double dot[K];
 #pragma unroll
@@ -317,6 +352,8 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
         block_sum<K>(dot, smem);
         if (tid < K) ppart[p * K + tid] = pick<K>(dot, tid);
     }
+    REMO_STAMP(7)
+#undef REMO_STAMP
 }
 
 // Rows shared by several patches: sum of the row's slab slots in ascending patch order.  DOT: the patches' <x, A x> are folded
@@ -362,10 +399,12 @@ __global__ void __launch_bounds__(256) k_patch_reduce(int64_t n, int64_t npatch,
 }
 
 int g_patch_mode = 0;  // key 21: ablation mode of k_patch_apply (fp64, k = 5 only)
+long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of phase time stamps (remo_debug_patch_phases)
 
 }  // namespace
 
 void set_patch_mode(int mode) { g_patch_mode = mode; }
+void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
 int patch_elements_per_group(int kmax) { return 256 / (kmax > 0 ? kmax : 1); }   // one lane per (element, right-hand side)
 
@@ -401,7 +440,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     const size_t mark = ar.hi_mark();
     int32_t *bcnt = ar.hi<int32_t>(size_t(n) + 2);
     int32_t *pbcnt = ar.hi<int32_t>(size_t(out.npatch) + 2), *pboff = ar.hi<int32_t>(size_t(out.npatch) + 2);
-    (void)hipMemsetAsync(flag_and_max, 0, 2 * sizeof(int32_t), s);
+    (void)hipMemsetAsync(flag_and_max, 0, 3 * sizeof(int32_t), s);
     (void)hipMemsetAsync(prow, 0xFF, sizeof(int32_t) * (size_t(out.npatch) * rows_cap + 1), s);   // -1 behind a patch's last row
     (void)hipMemsetAsync(pbcnt + out.npatch, 0, sizeof(int32_t), s);
     hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt);
@@ -413,8 +452,10 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     void *tmp = ar.hi<char>((tb1 > tb2 ? tb1 : tb2) + 256);
     (void)rocprim::exclusive_scan(tmp, tb1, bcnt, bptr, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s);
     (void)rocprim::exclusive_scan(tmp, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
+    hipLaunchKernelGGL(k_patch_zero_rows, dim3(1024), dim3(256), 0, s, nt * 20, lidx, (const int32_t *)(flag_and_max + 1));
     hipLaunchKernelGGL(k_patch_slots, dim3(int(out.npatch)), dim3(256), 0, s, E, rows_cap, (const int32_t *)pcount, (const int32_t *)pboff, (const int32_t *)prow, pout,
                        sy.adjptr, sy.adj, (const int32_t *)bptr, bslot);
+    (void)hipMemcpyAsync(flag_and_max + 2, bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use
     ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
     out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.bptr = bptr; out.bslot = bslot;
 }
@@ -423,19 +464,22 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     const PatchOpT<T> &P = *A.patch;
     const PatchTables &tb = P.t;
     const int64_t per = (tb.npatch + 7) / 8;
-    const size_t lds = size_t(P.lds_rows + 2) * K * sizeof(T);
+    constexpr int kPass = kPatchPasses * (256 / K);
+    const size_t rows_pad = size_t((P.lds_rows + kPass - 1) / kPass) * kPass;
+    const size_t lds = ((size_t(P.lds_rows + 2) * K * sizeof(T) + 7) / 8) * 8 + rows_pad * 8;   // staged rows + the two (padded) row tables
     double *pp = part ? P.ppart : nullptr;
     bool launched = false;
     const dim3 grid(int(per * 8));
     if constexpr (K == 5 && sizeof(T) == 8) {     // ablations (tools/probe_patch.py)
-        if (g_patch_mode >= 1 && g_patch_mode <= 3) {
+        if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
             launched = true;
-            if (g_patch_mode == 1) hipLaunchKernelGGL((k_patch_apply<T, 5, 1>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
-            else if (g_patch_mode == 2) hipLaunchKernelGGL((k_patch_apply<T, 5, 2>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
-            else hipLaunchKernelGGL((k_patch_apply<T, 5, 3>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+            if (g_patch_mode == 1) hipLaunchKernelGGL((k_patch_apply<T, 5, 1>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
+            else if (g_patch_mode == 2) hipLaunchKernelGGL((k_patch_apply<T, 5, 2>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
+            else if (g_patch_mode == 3) hipLaunchKernelGGL((k_patch_apply<T, 5, 3>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
+            else hipLaunchKernelGGL((k_patch_apply<T, 5, 4>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, g_patch_stamps);
         }
     }
-    if (!launched) hipLaunchKernelGGL((k_patch_apply<T, K>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step);
+    if (!launched) hipLaunchKernelGGL((k_patch_apply<T, K>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
     if (part) hipLaunchKernelGGL((k_patch_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)P.ppart, part, scal, step);
     else hipLaunchKernelGGL((k_patch_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)nullptr, part, scal, step);
 }

@@ -75,6 +75,24 @@ double mean(const Poly &p, int dim) {
     return (double)s;
 }
 
+// mean_T of a polynomial by a QUADRATURE RULE instead of the exact formula (2D only): the 6-point rule of Strang and Fix /
+// Dunavant, exact to degree 4 - one order below the degree-5 integrand of the axisymmetric form.  Which rule NGSolve's
+// SymbolicBFI applies to `2 pi x sigma grad(u) grad(v)` (ngsolve_functions.py:34) is part of the un-pinned third-party
+// arithmetic; this is the alternative SURVEY.md section 7.3-2 asks to have pluggable (remo_opts_t.quadrature = 1).
+double mean_rule4(const Poly &p) {
+    static const double a1 = 0.445948490915965, b1 = 0.108103018168070, w1 = 0.223381589678011;
+    static const double a2 = 0.091576213509771, b2 = 0.816847572980459, w2 = 0.109951743655322;
+    const double pts[6][3] = {{b1, a1, a1}, {a1, b1, a1}, {a1, a1, b1}, {b2, a2, a2}, {a2, b2, a2}, {a2, a2, b2}};
+    const double wts[6] = {w1, w1, w1, w2, w2, w2};
+    long double s = 0;
+    for (int q = 0; q < 6; ++q) {
+        long double v = 0;
+        for (const auto &m : p) v += (long double)m.c * std::pow(pts[q][0], m.e[0]) * std::pow(pts[q][1], m.e[1]) * std::pow(pts[q][2], m.e[2]);
+        s += wts[q] * v;
+    }
+    return (double)s;
+}
+
 std::vector<Poly> basis(int dim) {
     std::vector<Poly> phi;
     for (int i = 0; i <= dim; ++i) phi.push_back(mono(1.0, i, 1));
@@ -96,7 +114,7 @@ std::vector<Poly> basis(int dim) {
     return phi;
 }
 
-std::vector<double> build(int dim) {
+std::vector<double> build(int dim, int rule = 0) {
     const int n = (dim == 2) ? 10 : 20;
     const auto phi = basis(dim);
     // D[a][i] = d phi_i / d xi_a, a = 1..dim
@@ -110,7 +128,7 @@ std::vector<double> build(int dim) {
                 Poly p = mul(D[a][i], D[b][j]);
                 if (a != b) p = add(p, mul(D[b][i], D[a][j]));
                 if (k >= 0) p = mul(p, mono(1.0, k, 1));
-                M.push_back(mean(p, dim));
+                M.push_back((rule == 1 && dim == 2) ? mean_rule4(p) : mean(p, dim));
             }
     };
     if (dim == 3) {
@@ -189,6 +207,13 @@ double ref_factors3_error() {
                     if (e > worst) worst = e;
                 }
     return worst;
+}
+
+const double *ref_tables2_rule4() {
+    static std::once_flag f;
+    static std::vector<double> t;
+    std::call_once(f, [] { t = build(2, 1); });
+    return t.data();
 }
 
 const double *ref_tables(int dim) {

@@ -57,7 +57,7 @@ struct remo_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     Arena ar;
-    double *d_M2 = nullptr, *d_M3 = nullptr;
+    double *d_M2 = nullptr, *d_M3 = nullptr, *d_M2q = nullptr;   // reference tensors: exact 2D / 3D, 2D by the degree-4 rule
     PcgProgress *progress = nullptr;  // mapped, coherent host memory
     PcgProgress *progress_dev = nullptr;
     int progress_len = 0;
@@ -117,6 +117,7 @@ struct remo_batch {
     AmgT<double> amg64{};                   // multigrid hierarchy of the vertex block of the last run (arena)
     AmgT<float> amg32{};
     int k_last = 0;
+    const double *d_M_last = nullptr;       // reference tensors of the last run (remo_opts_t.quadrature)
     uint64_t run_id = 0;
     std::vector<double> u_out;
 };
@@ -382,6 +383,8 @@ remo_ctx_t *remo_ctx_create(int device_id) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_M3), sizeof(double) * 6 * 400));
         HIP_TRY(hipMemcpy(ctx->d_M2, m2, sizeof(double) * 9 * 100, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_M3, m3, sizeof(double) * 6 * 400, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_M2q), sizeof(double) * 9 * 100));
+        HIP_TRY(hipMemcpy(ctx->d_M2q, ref_tables2_rule4(), sizeof(double) * 9 * 100, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_err), sizeof(int32_t)));
         ctx->ensure_progress(1024 + 2);
         return ctx;
@@ -402,6 +405,7 @@ void remo_ctx_destroy(remo_ctx_t *ctx) {
     if (ctx->ar.base) hipFree(ctx->ar.base);
     if (ctx->d_M2) hipFree(ctx->d_M2);
     if (ctx->d_M3) hipFree(ctx->d_M3);
+    if (ctx->d_M2q) hipFree(ctx->d_M2q);
     if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->progress) hipHostFree(ctx->progress);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -603,7 +607,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         HIP_TRY(hipEventRecord(ctx->ev[1], s));
 
         // ---- assembly ---------------------------------------------------------------------
-        const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
+        const double *d_M = (dim == 2) ? (o.quadrature == 1 ? ctx->d_M2q : ctx->d_M2) : ctx->d_M3;
+        b->d_M_last = d_M;
         launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, sy.eperm, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
         int64_t pair_begin = 0, pair_end = 0;   // edge-dof rows: consecutive pairs with identical patterns, values interleaved
         if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { pair_begin = sy.nvfree; pair_end = sy.nvefree; }
@@ -661,12 +666,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         }
         // patch operator (patch.hip): its tables are built beside the assembly; their overflow flag and largest patch come
         // back with the other small read-backs below
-        int32_t h_patch[2] = {1, 0};
+        int32_t h_patch[3] = {1, 0, 0};
         PatchTables ptab{};
         if (want_patch) {
-            int32_t *d_pflag = ctx->take<int32_t>(2);
+            int32_t *d_pflag = ctx->take<int32_t>(4);
             build_patch_tables(ctx->ar, s, sy, d_C, kmax, ptab, d_pflag);
-            HIP_TRY(hipMemcpyAsync(h_patch, d_pflag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h_patch, d_pflag, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -715,12 +720,14 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const bool elem_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
         // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
-        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits;
+        // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24);
         if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
         const bool patch_op = patch_ok && (o.op == 3 || (o.op == 0 && g_auto_patch));
         const bool elem_op = !patch_op && dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
         st->op_used = patch_op ? 3 : (elem_op ? 1 : 0);
         if (patch_op) {
+            ptab.nslot_cap = h_patch[2] > 0 ? h_patch[2] : 1;     // the slab holds the slots in use
             b->patch64 = PatchOpT<double>{ptab, ctx->take<double>(size_t(ptab.nslot_cap) * size_t(kmax) + 8), ctx->take<double>(size_t(ptab.npatch) * 8 + 8), h_patch[1]};
             b->A.patch = &b->patch64;
         }
@@ -915,7 +922,7 @@ int remo_batch_eval(remo_ctx_t *ctx, remo_batch_t *b, int32_t rhs, int32_t npts,
         for (int q0 = 0; q0 < npts; q0 += kMaxPoints)
             launch_locate(dim, b->nt, b->d_coords, sy.conn, std::min(kMaxPoints, npts - q0), d_z + q0, d_found + q0, s);
         launch_point_shapes(dim, npts, d_z, d_found, b->d_coords, sy.conn, d_phi, ctx->d_err, s);
-        const double *d_M = (dim == 2) ? ctx->d_M2 : ctx->d_M3;
+        const double *d_M = b->d_M_last ? b->d_M_last : ((dim == 2) ? ctx->d_M2 : ctx->d_M3);
         launch_eval(dim, sy.condense, npts, d_rhs, d_I, d_found, d_phi, sy.eldof, b->d_C, d_M, b->k_last, b->d_x, d_fint, d_out, s);
         int32_t h_err = 0;
         HIP_TRY(hipMemcpyAsync(u_out, d_out, sizeof(double) * npts, hipMemcpyDeviceToHost, s));
@@ -1217,6 +1224,55 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     } catch (const std::exception &ex) {
         if (dx) (void)hipFree(dx);
         if (dy) (void)hipFree(dy);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+}
+
+int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, double *out16) {
+    if (!ctx || !b || !out16) return REMO_ERR_ARG;
+    if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");
+    const int k = 5;
+    if (k * b->patch64.t.E > 256) return fail(ctx, REMO_ERR_ARG, "the batch's patch tables are laid out for fewer than 5 columns");
+    double *dx = nullptr, *dy = nullptr;
+    long long *st = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int64_t n = b->A.n, grid = (b->patch64.t.npatch + 7) / 8 * 8;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * (n * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dy), sizeof(double) * (n * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st), sizeof(long long) * grid * 8));
+        std::vector<double> hx(size_t(n) * k);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        HIP_TRY(hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(st, 0, sizeof(long long) * grid * 8));
+        const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
+        set_patch_stamps(st); set_patch_mode(4);
+        for (int rep = 0; rep < 3; ++rep) launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
+        set_patch_mode(0); set_patch_stamps(nullptr);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<long long> h(size_t(grid) * 8);
+        HIP_TRY(hipMemcpy(h.data(), st, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(st);
+        for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+        long long lo = LLONG_MAX, hi = 0;
+        int64_t cnt = 0;
+        for (int64_t w = 0; w < grid; ++w) {
+            const long long *s8 = h.data() + w * 8;
+            if (s8[0] == 0 || s8[7] == 0) continue;
+            for (int q = 0; q < 7; ++q) out16[q] += double(s8[q + 1] - s8[q]);
+            out16[7] += double(s8[7] - s8[0]);
+            lo = std::min(lo, s8[0]); hi = std::max(hi, s8[7]);
+            ++cnt;
+        }
+        for (int q = 0; q < 8; ++q) out16[q] /= double(cnt > 0 ? cnt : 1);
+        out16[8] = double(hi - lo);     // first start to last end, clock ticks
+        out16[9] = double(cnt);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        set_patch_mode(0); set_patch_stamps(nullptr);
+        if (dx) (void)hipFree(dx);
+        if (dy) (void)hipFree(dy);
+        if (st) (void)hipFree(st);
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
 }

@@ -133,8 +133,8 @@ __device__ __forceinline__ int64_t find_key(const uint64_t *__restrict__ a, int6
 // global dof numbers of every element (before elimination)
 template <int DIM>
 __global__ void __launch_bounds__(256) k_eldof_global(int64_t nt, int64_t nv, int64_t ne, int64_t nf, const int32_t *__restrict__ conn,
-                                                      const uint64_t *__restrict__ eku, const uint64_t *__restrict__ fku, int nbits,
-                                                      int32_t *__restrict__ eldof) {
+                                                      const int32_t *__restrict__ eperm, const uint64_t *__restrict__ eku,
+                                                      const uint64_t *__restrict__ fku, int nbits, int32_t *__restrict__ eldof) {
     constexpr int NB = DIM + 1, NE = P3<DIM>::NEDGE, N = P3<DIM>::NLD;
     const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nt) return;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_eldof_global(int64_t nt, int64_t nv, in
             ed[k++] = int32_t(nv + 2 * ne + find_key(fku, nf, face_key(c[a], c[b], c[cc], nbits)));
         }
     } else {
-        ed[k++] = int32_t(nv + 2 * ne + t);  // cell bubble (dropped below when condensed)
+        ed[k++] = int32_t(nv + 2 * ne + (eperm ? int64_t(eperm[t]) : t));  // cell bubble, numbered by the caller's element order (dropped below when condensed)
     }
 }
 
@@ -459,8 +459,8 @@ int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt
     out.ndof = ndof;
 
     // ---- element dofs, Dirichlet flags, free numbering -----------------------------------------
-    if (dim == 2) hipLaunchKernelGGL(k_eldof_global<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, ne, nf, out.conn, eku, fku, nbits, out.eldof);
-    else hipLaunchKernelGGL(k_eldof_global<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, ne, nf, out.conn, eku, fku, nbits, out.eldof);
+    if (dim == 2) hipLaunchKernelGGL(k_eldof_global<2>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, ne, nf, out.conn, (const int32_t *)out.eperm, eku, fku, nbits, out.eldof);
+    else hipLaunchKernelGGL(k_eldof_global<3>, dim3(grid_for(nt)), dim3(256), 0, s, nt, nv, ne, nf, out.conn, (const int32_t *)out.eperm, eku, fku, nbits, out.eldof);
     out.freeid = ar.lo<int32_t>(ndof);
     const size_t hi_mark1 = ar.hi_mark();
     int32_t *isfree = ar.hi<int32_t>(ndof), *scan = ar.hi<int32_t>(ndof);

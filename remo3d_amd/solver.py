@@ -25,7 +25,7 @@ class RemoError(RuntimeError):
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
               time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0,
-              serialize_solves=False, op="auto", coarse="auto") -> RemoOpts:
+              serialize_solves=False, op="auto", coarse="auto", quadrature="exact") -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
     precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
     (BASELINE config 5); inner_digits: decimal digits of <Cr,r> between two residual replacements (0 = library default 3)."""
@@ -53,6 +53,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     if coarse not in ("auto", "chebyshev", "amg"):
         raise ValueError("coarse must be 'auto' (multigrid cycle in 2D, Chebyshev polynomial in 3D), 'chebyshev' or 'amg'")
     o.coarse = {"auto": 0, "chebyshev": 1, "amg": 2}[coarse]   # solver of the P1 block inside "multigrid"
+    if quadrature not in ("exact", "degree4"):
+        raise ValueError("quadrature must be 'exact' or 'degree4' (2D reference tensors by the 6-point rule)")
+    o.quadrature = 1 if quadrature == "degree4" else 0
     return o
 
 

@@ -51,6 +51,12 @@ def main():
                            u0=float(u[0]))
                 out.append(rec)
                 print(json.dumps(rec), flush=True)
+                if name == "patch":
+                    import ctypes as C
+                    ph = (C.c_double * 16)()
+                    if L.remo_debug_patch_phases(ctx._h, b._h, ph) == 0:
+                        names = ["tables", "stage x", "x->regs", "zero", "arith+accumulate", "output", "partials", "workgroup", "launch span", "workgroups"]
+                        print("phases (clock ticks): " + "  ".join("%s %.0f" % (nm, ph[i]) for i, nm in enumerate(names)), flush=True)
             b.close()
     return out
 

@@ -65,10 +65,19 @@ def _build_some(job):
     m, depths, sim, batches, mud, bg = _model_and_batches(n_depths)
     provider = default_mesh_provider(scale=scale, seed=0, mesh_3d=mesh_3d)
     out = []
+    trace = os.environ.get("REMO_BENCH_TRACE_MESH") == "1"
     for bi in indices:
         b = batches[bi]
         fg, bh, sigma = geometry.select_data_range(bg, m.formation_model, m.dip_rad, mud[bi], sim[bi], 50.0)
+        t0 = time.time()
+        if trace:
+            import faulthandler
+            faulthandler.dump_traceback_later(60, repeat=False)
+            sys.stderr.write("[mesh worker %d] start scale %.2f %s batch %d\n" % (os.getpid(), scale, mesh_3d, bi)); sys.stderr.flush()
         mesh = provider(3, 50.0, b, fg, bh, m.dip_rad)
+        if trace:
+            faulthandler.cancel_dump_traceback_later()
+            sys.stderr.write("[mesh worker %d] done  scale %.2f %s batch %d: T = %d in %.1f s\n" % (os.getpid(), scale, mesh_3d, bi, mesh.n_elems, time.time() - t0)); sys.stderr.flush()
         sources, evals, readers = tasks.batch_rhs(b, m.tools)
         out.append(dict(index=bi, mesh=mesh, sigma=sigma, sources=sources, evals=evals, readers=readers))
     return out
@@ -101,22 +110,39 @@ def _build_some_2d(indices):
     return out
 
 
-def build_workload_2d(nb, pool=None):
+class Pending:
+    """A workload whose meshes are being built in the pool: one job per batch, all workloads of the run submitted before any
+    is waited for (the pool stays full; a two-batch XL workload no longer holds two workers while eight idle)."""
+
+    def __init__(self, meta, futs, t0):
+        self.meta, self.futs, self.t0 = meta, futs, t0
+
+    def result(self, note=None):
+        work = []
+        for f in self.futs:
+            work.extend(f.result())
+            if note:
+                note(len(work), len(self.futs))
+        self.meta["work"] = sorted(work, key=lambda w: w["index"])
+        self.meta["mesh_s"] = time.time() - self.t0
+        return self.meta
+
+
+def build_workload_2d(nb, pool=None, wait=True):
     """BASELINE configs[1]: Benchmark model 1 (2D axisymmetric), tool A0.4M6.0N, 100 depths in batches of 5, default mesh
     scale (the one that meets the reference's logs): nb of the 20 batches, evenly spread over the log."""
     m, depths, sim, batches, mud, bg = _model_and_batches_2d()
     mine = list(range(0, len(batches), max(1, len(batches) // nb)))[:nb]
+    meta = dict(model=m, depths=depths, n_batches=len(batches), names=["A0.4M6.0N"])   # the slab of results is indexed by the depth's place in the whole log
     if pool is not None and len(mine) > 1:
-        nw = getattr(pool, "_max_workers", 4)
-        futs = [pool.submit(_build_some_2d, mine[i::nw]) for i in range(nw) if mine[i::nw]]
-        work = sorted((w for f in futs for w in f.result()), key=lambda w: w["index"])
-    else:
-        work = _build_some_2d(mine)
-    return dict(model=m, depths=depths, n_batches=len(batches), work=work, names=["A0.4M6.0N"])   # the slab of results is indexed by the depth's place in the whole log
+        pend = Pending(meta, [pool.submit(_build_some_2d, [i]) for i in mine], time.time())
+        return pend.result() if wait else pend
+    meta["work"] = _build_some_2d(mine)
+    return meta
 
 
 def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice", total_depths=None, all_batches=False, max_batches=None,
-                   pool=None):
+                   pool=None, wait=True):
     """Batches of this rank (block-cyclic share; all of them when all_batches) with meshes and right-hand sides.
     pool: a concurrent.futures executor of CPU-only processes that build the meshes side by side."""
     n_depths = int(total_depths) if total_depths else depths_per_gpu * world
@@ -125,14 +151,13 @@ def build_workload(rank, world, depths_per_gpu, scale, dim=3, mesh_3d="lattice",
     if max_batches:
         mine = mine[:max_batches]
     t0 = time.time()
+    meta = dict(model=m, depths=depths, n_batches=len(batches), names=list(TOOLS))
     if pool is not None and len(mine) > 1:
-        nw = getattr(pool, "_max_workers", 4)
-        chunks = [mine[i::nw] for i in range(nw) if mine[i::nw]]
-        futs = [pool.submit(_build_some, (n_depths, scale, mesh_3d, c)) for c in chunks]
-        work = sorted((w for f in futs for w in f.result()), key=lambda w: w["index"])
-    else:
-        work = _build_some((n_depths, scale, mesh_3d, mine))
-    return dict(model=m, depths=depths, n_batches=len(batches), work=work, mesh_s=time.time() - t0, names=list(TOOLS))
+        pend = Pending(meta, [pool.submit(_build_some, (n_depths, scale, mesh_3d, [i])) for i in mine], t0)
+        return pend.result() if wait else pend
+    meta["work"] = _build_some((n_depths, scale, mesh_3d, mine))
+    meta["mesh_s"] = time.time() - t0
+    return meta
 
 
 def _cpu_leg_main(path):
@@ -430,7 +455,7 @@ def main():
                     help="with --streams > 1: 'prepare' = only one batch is in its PCG at a time, the other contexts number / assemble "
                          "theirs beside it; 'all' = no restriction")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--sizes", default="L/csr:4,L/mixed:4,S:8,S/csr:8,M:8,XL:2,XL/mixed:2,conforming-M:8,2D-BM1:8,2D-BM1/2ctx:8",
+    ap.add_argument("--sizes", default="L/csr:4,L/mixed:4,S:8,S/csr:8,M:8,XL:2,XL/mixed:2,conforming-M:8,2D-BM1:8",
                     help="further workloads measured in the same run at N = 1 (SIZE:batches, 'conforming-' prefix = conforming meshes, "
                          "'/mixed' = fp32 PCG in fp64 refinement, '/element' / '/csr' = that operator instead of the choice by size; '2D-BM1' = BASELINE configs[1], "
                          "Benchmark model 1 in 2D, '/chebyshev' = polynomial instead of the multigrid cycle on the vertex block, '/2ctx' = two contexts (streams, host threads) share the batches), reported in the `sizes` array; '' = none")
@@ -480,15 +505,42 @@ def main():
         from concurrent.futures import ProcessPoolExecutor
         mesh_pool = ProcessPoolExecutor(max_workers=args.mesh_workers, mp_context=multiprocessing.get_context("spawn"))
     t_mesh0 = time.time()
+    if mesh_pool is not None:
+        os.environ.setdefault("OMP_NUM_THREADS", "1")      # inherited by the spawned mesh workers: one thread each
+    # every workload of the run is SUBMITTED before any is waited for; XL first (its meshes take longest)
+    pending = {}
+    for name, size, kind, nb in sorted(extra_specs, key=lambda e: -{"XL": 3, "L": 2, "M": 1}.get(e[1], 0)):     # the 20-depth sweep of the same model; variants of one size share its meshes
+        if (size, kind, nb) not in pending and not (size == args.size and kind == args.mesh):
+            pending[(size, kind, nb)] = (build_workload_2d(nb, pool=mesh_pool, wait=False) if kind == "2D" else
+                                         build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool, wait=False))
     wl = build_workload(rank, world, args.depths, SIZES[args.size], mesh_3d=args.mesh, total_depths=args.total_depths or None,
-                        all_batches=dynamic, pool=mesh_pool)
+                        all_batches=dynamic, pool=mesh_pool, wait=False)
+
+    def progress(what):
+        return lambda done, total: log("meshes: %s %d / %d" % (what, done, total)) if (done % 5 == 0 or done == total) else None
+    all_futs = [f for pend in list(pending.values()) + [wl] if isinstance(pend, Pending) for f in pend.futs]
+    import threading
+    stop_beat = threading.Event()
+
+    def beat():       # the mesh phase of the reference-resolution workload takes minutes: say so while it lasts
+        while not stop_beat.wait(30.0):
+            log("meshing: %d of %d mesh jobs done" % (sum(f.done() for f in all_futs), len(all_futs)))
+    if all_futs:
+        threading.Thread(target=beat, daemon=True).start()
+    if isinstance(wl, Pending):
+        wl = wl.result(progress("headline workload"))
     built = {}
+    for key, pend in pending.items():
+        built[key] = pend.result(progress("%s (%s)" % (key[0], key[1]))) if isinstance(pend, Pending) else pend
     extra_wl = []
-    for name, size, kind, nb in extra_specs:     # the 20-depth sweep of the same model: 8 batches; variants of one size share its meshes
-        if (size, kind, nb) not in built:
-            built[(size, kind, nb)] = (build_workload_2d(nb, pool=mesh_pool) if kind == "2D" else
-                                       build_workload(0, 1, 20, SIZES[size], mesh_3d=kind, max_batches=nb, pool=mesh_pool))
-        extra_wl.append((name, built[(size, kind, nb)]))
+    for name, size, kind, nb in extra_specs:
+        if size == args.size and kind == args.mesh:     # variants of the headline size run on the headline's own first batches
+            w2 = dict(wl)
+            w2["work"] = wl["work"][:nb]
+            extra_wl.append((name, w2))
+        else:
+            extra_wl.append((name, built[(size, kind, nb)]))
+    stop_beat.set()
     if mesh_pool is not None:
         mesh_pool.shutdown()
     mesh_wall = time.time() - t_mesh0

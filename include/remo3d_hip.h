@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 5
+#define REMO_ABI_VERSION 6
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -90,6 +90,13 @@ typedef struct {
                                    the polynomial of degree 28 at a quarter of its launches), the polynomial in 3D (there it is
                                    within 15 % of an exact vertex solve at degree 5-13 and the cycle gains nothing).
                                If the hierarchy cannot be built (a vertex of extreme valence) 0 falls back to the polynomial, 2 fails */
+    int32_t assemble;       /* what a 3D batch that runs on the patch operator assembles (CGSolver's a.mat is never read there):
+                               0 = by size (default): the whole matrix up to 200 k tetrahedra (inspection hooks, small cost), above that only
+                                   the Jacobi diagonal and the P1 (vertex) block the preconditioner solves - pattern and values of a
+                                   2 M-row matrix are 4.5 ms of an 80 ms batch and 1.2 GB;
+                               1 = always the whole matrix; 2 = diagonal + P1 block whenever the patch operator runs.
+                               Without the matrix remo_batch_get_system (rowptr / col / val) and products with more columns than the
+                               batch has right-hand sides fail with REMO_ERR_ARG; op = 1 / 2 always assemble */
     int32_t quadrature;     /* 2D: how the reference tensors of `2 pi x sigma grad(u) grad(v)` (ngsolve_functions.py:34; a degree-5 integrand) are
                                integrated: 0 = exactly (default); 1 = by the 6-point rule that is exact to degree 4 - the alternative NGSolve
                                may be using (its rule order is not pinned by the reference).  3D integrands have degree 4: always exact */
@@ -119,7 +126,7 @@ typedef struct {
     double event_overhead_ms; /* elapsed time of an EMPTY hipEvent pair on the stream (min of 16),
                             i.e. what a bracket measures beyond the kernel it encloses             */
     int64_t refinement_cycles; /* mixed precision: fp32 inner solves that contributed a correction (all chunks) */
-    int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 1 = element by element (remo_opts_t.op) */
+    int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 1 = element by element, 3 = patch operator (remo_opts_t.op) */
     int32_t coarse_used; /* vertex-block solver of the run: 0 = none ("local"), 1 = Chebyshev polynomial, 2 = multigrid cycle */
 } remo_stats_t;
 

@@ -25,7 +25,7 @@ class RemoOpts(C.Structure):
     _fields_ = [("preconditioner", C.c_int32), ("condense", C.c_int32), ("maxsteps", C.c_int32),
                 ("check_every", C.c_int32), ("rtol", C.c_double), ("time_kernels", C.c_int32),
                 ("coarse_degree", C.c_int32), ("coarse_ratio", C.c_int32), ("precision", C.c_int32), ("inner_digits", C.c_int32),
-                ("serialize_solves", C.c_int32), ("op", C.c_int32), ("coarse", C.c_int32), ("quadrature", C.c_int32)]
+                ("serialize_solves", C.c_int32), ("op", C.c_int32), ("coarse", C.c_int32), ("assemble", C.c_int32), ("quadrature", C.c_int32)]
 
 
 class RemoStats(C.Structure):

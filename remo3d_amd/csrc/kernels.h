@@ -49,6 +49,10 @@ template <class T> struct PcgBuffersT {
     // multigrid cycle on the vertex block instead of the polynomial (amg.h; 2D by default); nullptr -> Chebyshev
     const AmgT<T> *amg = nullptr;
     const AmgT<float> *amg32 = nullptr;   // fp64 solves: the cycle in fp32 storage (remo_debug_tune key 17), nullptr -> in T
+    // patch operator only: q = A p is left WITHOUT the sums of the rows shared by several patches - the update launch, which reads
+    // q once anyway, forms them from the boundary slab itself (one launch and one pass over the slab less per step).  Set by the
+    // host when the operator is the patch operator and the update launch does not gather q (no folded Chebyshev step).
+    bool defer_q = false;
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
@@ -73,8 +77,9 @@ void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint3
 // Patch operator (3D, remo_opts_t.op = 3; patch.hip): the element list cut into runs of E elements, one workgroup each
 struct PatchTables {
     int64_t nt = 0, n = 0, npatch = 0;
-    int E = 0;                         // elements per patch = 256 / right-hand sides of the batch (one lane per element and column)
+    int E = 0;                         // elements per patch = block / right-hand sides of the batch (one lane per element and column)
     int rows_cap = 0;                  // rows of prow / pout per patch
+    int block = 256;                   // threads per workgroup the tables were laid out for (256 or 512)
     const uint16_t *lidx = nullptr;    // [nt][20] local row of every element dof inside its patch, 0xFFFF = constrained
     const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
     const int32_t *prow = nullptr;     // [npatch][rows_cap] matrix row of local row m, ascending
@@ -102,6 +107,7 @@ template <class T> struct CsrViewT {
     int64_t pair_begin = 0, pair_end = 0;
     const ElemOpT<T> *elem = nullptr;   // != nullptr: launch_spmm applies the element-wise operator instead of the stored entries
     const PatchOpT<T> *patch = nullptr; // != nullptr: launch_spmm applies the patch operator (patch.hip)
+    bool vertex_block_only = false;     // rowptr / col / val hold only the leading P1 block (rows and columns < the free vertex count): products need `patch`
 };
 using CsrView = CsrViewT<double>;
 
@@ -109,6 +115,7 @@ void launch_metric_terms(int dim, int64_t nt, const double *coords, const int32_
                          const double *sigma, int nmat, double *C, int32_t *errflag, hipStream_t s);
 // rows [pair_begin, pair_end) (the two dofs of every free edge) get their values interleaved: entry e of the first row
 // at rowptr[row] + 2e, of the second at rowptr[row] + 2e + 1 (CsrViewT below); all other rows plain CSR
+void launch_diag_rows(int dim, int64_t row0, int64_t nfree, const int32_t *adjptr, const uint32_t *adj, const double *C, const double *M, double *dinv, hipStream_t s);
 void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr, const int32_t *col,
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s);
@@ -120,10 +127,14 @@ void set_spmm_tuning(int key, int value);  // 0 variant, 1 lanes per row, 2 thre
 int choose_lanes_per_row(int64_t n, int64_t nnz);
 // y = A x for k interleaved columns; if part != nullptr also leaves per-block partial sums of <x_c, y_c>
 // scal != nullptr: the launch belongs to PCG step `step` and returns at once when an earlier step froze every column
-template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step = 0);
+template <class T> bool patch_applies(const CsrViewT<T> &A, int k);   // launch_spmm will take the patch operator for k columns
+// defer = true (patch operator inside the PCG): rows shared by several patches are NOT summed into y (PcgBuffersT::defer_q)
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step = 0, bool defer = false);
 
-template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step);   // patch.hip
+template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step, bool defer);   // patch.hip
+template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
+void set_patch_block(int threads);   // 256 (default) or 512
 void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps
 int patch_elements_per_group(int kmax);
 

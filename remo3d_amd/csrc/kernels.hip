@@ -221,6 +221,36 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
     }
 }
 
+// Jacobi factors of rows [row0, nfree) WITHOUT the assembled matrix (the patch operator's batches assemble only the P1 block):
+// diagonal entry = sum over the row's incident elements of K_e[li][li].  One thread per row, same element order as the assembly.
+template <int DIM>
+__global__ void __launch_bounds__(256) k_diag_rows(int64_t row0, int64_t nfree, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
+                                                   const double *__restrict__ C, const double *__restrict__ Mg, double *__restrict__ dinv) {
+    constexpr int N = P3<DIM>::NLD, NT = P3<DIM>::NTERM;
+    __shared__ double Md[NT * N];
+    for (int i = threadIdx.x; i < NT * N; i += blockDim.x) Md[i] = Mg[((i / N) * N + (i % N)) * N + (i % N)];
+    __syncthreads();
+    const int64_t row = row0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= nfree) return;
+    double s = 0.0;
+    for (int32_t a = adjptr[row]; a < adjptr[row + 1]; ++a) {
+        const uint32_t code = adj[a];
+        const double *c = C + int64_t(code >> 5) * NT;
+        const int li = int(code & 31u);
+        double e = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) e += c[t] * Md[t * N + li];
+        s += e;
+    }
+    dinv[row] = 1.0 / s;
+}
+void launch_diag_rows(int dim, int64_t row0, int64_t nfree, const int32_t *adjptr, const uint32_t *adj, const double *C, const double *M, double *dinv, hipStream_t s) {
+    if (nfree <= row0) return;
+    const int grid = int((nfree - row0 + 255) / 256);
+    if (dim == 3) hipLaunchKernelGGL(k_diag_rows<3>, dim3(grid), dim3(256), 0, s, row0, nfree, adjptr, adj, C, M, dinv);
+    else hipLaunchKernelGGL(k_diag_rows<2>, dim3(grid), dim3(256), 0, s, row0, nfree, adjptr, adj, C, M, dinv);
+}
+
 void launch_assemble(int dim, bool condense, int64_t nfree, int64_t pair_begin, int64_t pair_end, const int32_t *rowptr, const int32_t *col,
                      const int32_t *adjptr, const uint32_t *adj, const int32_t *eldof, const double *C,
                      const double *M, double *val, double *dinv, hipStream_t s) {
@@ -544,7 +574,7 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
             buf_load<T, 2>(rx, ed[i] >= 0 ? (uint32_t(ed[i]) * K + c0) * S : kOutOfRange, w);
             xv[i].x = w[0]; xv[i].y = two ? w[1] : T(0);
         }
-        REMO_ELEM_GRAD(T2, xv, g, ElemTables<T>::grad())
+        REMO_ELEM_GRAD_LIT(T2, xv, g)
 #pragma unroll
         for (int m = 0; m < 10; ++m) {     // h = c~ g, in place
             const T2 g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
@@ -552,7 +582,7 @@ __global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64
             g[10 + m] = c12 * g1 + c22 * g2 + c23 * g3;
             g[20 + m] = c13 * g1 + c23 * g2 + c33 * g3;
         }
-        REMO_ELEM_DIV(T2, g, y, ElemTables<T>::div())
+        REMO_ELEM_DIV_LIT(T2, g, y)
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const uint32_t off = sl[i] >= 0 ? (uint32_t(sl[i]) * K + c0) * S : kOutOfRange;
@@ -708,11 +738,17 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 #undef REMO_SPMM_PAIR
 }
 
-template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
+template <class T> bool patch_applies(const CsrViewT<T> &A, int k) {
+    return A.patch && k * A.patch->t.E <= A.patch->t.block && size_t(A.patch->lds_rows + 2) * k * sizeof(T) + size_t(A.patch->lds_rows + 12 * (A.patch->t.block / k)) * 8 <= 60 * 1024;
+}
+template bool patch_applies<double>(const CsrViewT<double> &, int);
+template bool patch_applies<float>(const CsrViewT<float> &, int);
+
+template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step, bool defer) {
     // patch operator (patch.hip): its tables are laid out for the batch's own column count - a product with more columns than
     // that (inspection hooks only) goes through the stored matrix
-    if (A.patch && k * A.patch->t.E <= 256 && size_t(A.patch->lds_rows + 2) * k * sizeof(T) + size_t(A.patch->lds_rows + 12 * (256 / k)) * 8 <= 60 * 1024) {
-        launch_patch_spmm(A, k, x, y, part, scal, nb, s, step);
+    if (patch_applies(A, k)) {
+        launch_patch_spmm(A, k, x, y, part, scal, nb, s, step, defer);
         return;
     }
     if (A.elem) {     // element-wise operator instead of the stored matrix
@@ -739,8 +775,8 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
         default: spmm_dispatch<T, 8>(A, x, y, part, scal, step, nb, s); break;
     }
 }
-template void launch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int);
-template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int);
+template void launch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int, bool);
+template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int, bool);
 
 // ------------------------------------------------------------------------------------------
 // Jacobi-PCG vector kernels (CGSolver(a.mat, c.mat), ngsolve_functions.py:50-51), K columns at
@@ -768,6 +804,11 @@ template <class T> struct ChebArgsT {
     T *d0;            // [nv][K] first Chebyshev direction
 };
 // FIRST Chebyshev step folded into the update launch (k_pcg_update): nb_flat = 0 switches it off
+// q = A p of the patch operator with the rows shared by several patches still in the boundary slab (PcgBuffersT::defer_q)
+template <class T> struct QViewT {
+    const int32_t *bptr = nullptr, *bslot = nullptr;
+    const T *Yb = nullptr;
+};
 template <class T> struct FoldArgsT {
     int nb_flat = 0;             // workgroups [0, nb_flat) do the flat update of the rows >= nv, the rest the vertex rows
     const int32_t *rowptr = nullptr, *col = nullptr;
@@ -813,7 +854,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const T *__restrict__ p,
                                                     const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
-                                                    const T *__restrict__ dinv, FoldArgsT<T> fold) {
+                                                    const T *__restrict__ dinv, FoldArgsT<T> fold, QViewT<T> qv) {
     // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
@@ -913,11 +954,26 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
     for (int64_t i = i0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(nb_flat) * blockDim.x) {
         const T d = dinv[i];
         const bool coarse = i < ch.nv;
+        T qi[K];
+        int32_t b0 = 0, b1 = 0;
+        if (qv.bptr) { b0 = qv.bptr[i]; b1 = qv.bptr[i + 1]; }
+        if (b1 > b0) {      // a row shared by several patches: its q is still spread over the slab, one slot per patch, ascending
+#pragma unroll
+            for (int c = 0; c < K; ++c) qi[c] = T(0);
+            for (int32_t sl = b0; sl < b1; ++sl) {
+                const int64_t at = qv.bslot[sl];
+#pragma unroll
+                for (int c = 0; c < K; ++c) qi[c] += qv.Yb[at * K + c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < K; ++c) qi[c] = q[i * K + c];
+        }
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const T a = T(alpha[c]);
             const T xi = x[i * K + c] + a * p[i * K + c];
-            const T ri = r[i * K + c] - a * q[i * K + c];
+            const T ri = r[i * K + c] - a * qi[c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
             acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels
@@ -1390,6 +1446,10 @@ template <class T> static ChebArgsT<T> cheb_args(const PcgBuffersT<T> &b) {
 // behind the nb_vec partials of the high-order part (slot = even / odd step buffer)
 // the update launch can take the FIRST step along when the polynomial has launches of its own left to commit the
 // vertex residual (degree >= 3) and is not applied through the squared block (2D)
+template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b);
+template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b) { return cheb_first_folds(b); }
+template bool pcg_update_folds<double>(const PcgBuffersT<double> &);
+template bool pcg_update_folds<float>(const PcgBuffersT<float> &);
 template <class T> static bool cheb_first_folds(const PcgBuffersT<T> &b) {
     // measured in the bench, fold on vs off on one box: -2.3 % solve time at 12.8 k vertices, -0.9 % at 27 k, +0.4 % at 83 k
     // (there the step is real work, not launch latency): small vertex blocks only
@@ -1510,8 +1570,10 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
         fold.c1 = rho_new * rho; fold.c2 = 2.0 * rho_new / delta;      // the j = 0 coefficients of launch_cheb
         grid = g + int((b.nv_coarse + 31) / 32);   // the vertex workgroups leave no partial sums: one row group each
     }
+    QViewT<T> qv;
+    if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; }
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold));
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, qv));
     launch_cheb(A, k, step, b, nxt, s, folded);
 }
 
@@ -1550,7 +1612,7 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<float> ch = cheb_args(b);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>()));
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>(), QViewT<float>()));
     launch_mixed_accumulate(n * k, x64, b.x, 1, s);
     launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s, 0);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0, step));

@@ -34,7 +34,7 @@ namespace remo {
 namespace {
 
 constexpr int kPatchPasses = 12;                       // k_patch_apply: loads a lane keeps in flight
-constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192
+constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192 (E <= 256: patch_elements_per_group)
 constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
 
 // ---- tables ------------------------------------------------------------------------------------------------------------
@@ -183,7 +183,7 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One workgroup = one patch of E = 256 / K elements; lane = (element, right-hand side).
+// One workgroup of BLK threads = one patch of E = BLK / K elements; lane = (element, right-hand side).
 // The kernel is a chain of dependent memory round trips (tables -> x rows -> LDS -> ... -> stores) around ~1 us of arithmetic, so
 // everything a lane will need from the tables is requested BEFORE the first wait - the rows it stages and later writes out (two
 // per lane in registers; prow holds -1 behind a patch's last row, so no row count is needed first), where their results go, the
@@ -191,8 +191,8 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
 // <x, A x> is summed element by element as g . h (g = B x, h = c~ g: x^T B^T c~ B x): complete when this launch ends, no second
 // look at x.  MODE != 0: ablations for tools/probe_patch.py (wrong results on purpose): 1 = plain stores instead of the LDS
 // atomics, 2 = no tensor arithmetic (y = x), 3 = nothing leaves the workgroup.
-template <class T, int K, int MODE = 0>
-__global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+template <class T, int K, int BLK, int MODE = 0>
+__global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
                                                      double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps) {
     if (scal && solve_done(scal, step)) return;
     // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
     REMO_STAMP(0)
     constexpr int NL = K;
     constexpr int U = kPatchPasses;                      // loads in flight per lane: one trip over up to U * (256 / K) rows
-    constexpr int EK = 256 / K;                          // rows per pass of the staging / output phases
+    constexpr int EK = BLK / K;                          // rows per pass of the staging / output phases
     constexpr uint32_t S = sizeof(T);
     const int rows_pad = (rows + U * EK - 1) / (U * EK) * (U * EK);
     extern __shared__ double lds_raw[];
@@ -235,17 +235,17 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
     }
     // 1a. the patch's row tables into LDS (one round trip; the output phase finds them there again).  prow holds -1 behind a
     // patch's last row, so no row count has to arrive first; the LDS copies are padded with -1 to whole passes of 1b.
-    for (int m0 = tid; m0 < rows_pad; m0 += 4 * 256) {
+    for (int m0 = tid; m0 < rows_pad; m0 += 4 * BLK) {
         int32_t r[4], o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int m = m0 + 256 * u;
+            const int m = m0 + BLK * u;
             r[u] = m < rows ? prow[m] : -1;
             o[u] = m < rows ? pout[m] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int m = m0 + 256 * u;
+            const int m = m0 + BLK * u;
             if (m < rows_pad) { trow[m] = r[u]; tout[m] = o[u]; }
         }
     }
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_patch_apply(PatchTables tb, int rows, c
     }
     __syncthreads();        // every lane holds its x values: the staging area becomes the accumulators
     REMO_STAMP(3)
-    for (int j = tid; j < (rows + 1) * K; j += 256) xs[j] = T(0);
+    for (int j = tid; j < (rows + 1) * K; j += BLK) xs[j] = T(0);
     __syncthreads();
     REMO_STAMP(4)
     double d0 = 0.0;
@@ -398,6 +398,23 @@ __global__ void __launch_bounds__(256) k_patch_reduce(int64_t n, int64_t npatch,
     }
 }
 
+// <x, A x> of the patches folded into <= 1024 partial rows for the consumer (every workgroup takes a fixed subset): what
+// k_patch_reduce<DOT> does at its end, alone - for the PCG, whose update launch sums the shared rows itself
+template <int K>
+__global__ void __launch_bounds__(256) k_patch_dot(int64_t npatch, const double *__restrict__ ppart, double *__restrict__ part,
+                                                   const double *__restrict__ scal, int step) {
+    if (scal && solve_done(scal, step)) return;
+    double dot[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) dot[c] = 0.0;
+    for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < npatch; p += int64_t(gridDim.x) * blockDim.x)
+#pragma unroll
+        for (int c = 0; c < K; ++c) dot[c] += ppart[p * K + c];
+    __shared__ double smem[16 * K];
+    block_sum<K>(dot, smem);
+    if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
+}
+
 int g_patch_mode = 0;  // key 21: ablation mode of k_patch_apply (fp64, k = 5 only)
 long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of phase time stamps (remo_debug_patch_phases)
 
@@ -406,7 +423,10 @@ long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of pha
 void set_patch_mode(int mode) { g_patch_mode = mode; }
 void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
-int patch_elements_per_group(int kmax) { return 256 / (kmax > 0 ? kmax : 1); }   // one lane per (element, right-hand side)
+int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
+void set_patch_block(int b) { g_patch_block = (b == 512) ? 512 : 256; }
+// one lane per (element, right-hand side); at most 256 elements (the table builder sorts 20 slots per element in LDS)
+int patch_elements_per_group(int kmax) { const int e = g_patch_block / (kmax > 0 ? kmax : 1); return e < 256 ? e : 256; }
 
 size_t patch_arena_bytes(int64_t nt, int64_t n_max, int kmax) {
     const int E = patch_elements_per_group(kmax);
@@ -427,7 +447,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     if (rows_cap > E * 20) rows_cap = E * 20;
     int npad = 256;
     while (npad < E * 20) npad <<= 1;
-    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap;
+    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap; out.block = g_patch_block;
     out.npatch = (nt + E - 1) / E;
     out.C = C;
     uint16_t *lidx = ar.lo<uint16_t>(size_t(nt) * 20 + 8);
@@ -460,43 +480,61 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.bptr = bptr; out.bslot = bslot;
 }
 
-template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
+template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s, bool defer) {
     const PatchOpT<T> &P = *A.patch;
     const PatchTables &tb = P.t;
     const int64_t per = (tb.npatch + 7) / 8;
-    constexpr int kPass = kPatchPasses * (256 / K);
-    const size_t rows_pad = size_t((P.lds_rows + kPass - 1) / kPass) * kPass;
-    const size_t lds = ((size_t(P.lds_rows + 2) * K * sizeof(T) + 7) / 8) * 8 + rows_pad * 8;   // staged rows + the two (padded) row tables
     double *pp = part ? P.ppart : nullptr;
-    bool launched = false;
     const dim3 grid(int(per * 8));
-    if constexpr (K == 5 && sizeof(T) == 8) {     // ablations (tools/probe_patch.py)
+    double *pp2 = pp;
+    auto launch = [&](auto kernel, int blk) {
+        const int pass = kPatchPasses * (blk / K);
+        const size_t rows_pad = size_t((P.lds_rows + pass - 1) / pass) * pass;
+        const size_t bytes = ((size_t(P.lds_rows + 2) * K * sizeof(T) + 7) / 8) * 8 + rows_pad * 8;   // staged rows + the two (padded) row tables
+        hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps);
+    };
+    bool launched = false;
+    if constexpr (K == 5 && sizeof(T) == 8) {     // ablations and the phase probe (tools/probe_patch.py)
         if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
             launched = true;
-            if (g_patch_mode == 1) hipLaunchKernelGGL((k_patch_apply<T, 5, 1>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
-            else if (g_patch_mode == 2) hipLaunchKernelGGL((k_patch_apply<T, 5, 2>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
-            else if (g_patch_mode == 3) hipLaunchKernelGGL((k_patch_apply<T, 5, 3>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
-            else hipLaunchKernelGGL((k_patch_apply<T, 5, 4>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, g_patch_stamps);
+            if (tb.block == 512) {
+                if (g_patch_mode == 1) launch(k_patch_apply<T, 5, 512, 1>, 512);
+                else if (g_patch_mode == 2) launch(k_patch_apply<T, 5, 512, 2>, 512);
+                else if (g_patch_mode == 3) launch(k_patch_apply<T, 5, 512, 3>, 512);
+                else launch(k_patch_apply<T, 5, 512, 4>, 512);
+            } else {
+                if (g_patch_mode == 1) launch(k_patch_apply<T, 5, 256, 1>, 256);
+                else if (g_patch_mode == 2) launch(k_patch_apply<T, 5, 256, 2>, 256);
+                else if (g_patch_mode == 3) launch(k_patch_apply<T, 5, 256, 3>, 256);
+                else launch(k_patch_apply<T, 5, 256, 4>, 256);
+            }
         }
     }
-    if (!launched) hipLaunchKernelGGL((k_patch_apply<T, K>), grid, dim3(256), lds, s, tb, P.lds_rows, x, y, P.Yb, pp, scal, step, (long long *)nullptr);
+    if (!launched) {
+        if (tb.block == 512) launch(k_patch_apply<T, K, 512, 0>, 512);
+        else launch(k_patch_apply<T, K, 256, 0>, 256);
+    }
+    if (part && defer) {
+        hipLaunchKernelGGL(k_patch_dot<K>, dim3(nb), dim3(256), 0, s, tb.npatch, (const double *)P.ppart, part, scal, step);
+        return;
+    }
     if (part) hipLaunchKernelGGL((k_patch_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)P.ppart, part, scal, step);
     else hipLaunchKernelGGL((k_patch_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)nullptr, part, scal, step);
 }
 
-template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step) {
+template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nb, hipStream_t s, int step, bool defer) {
     switch (k) {
-        case 1: patch_dispatch<T, 1>(A, x, y, part, scal, step, nb, s); break;
-        case 2: patch_dispatch<T, 2>(A, x, y, part, scal, step, nb, s); break;
-        case 3: patch_dispatch<T, 3>(A, x, y, part, scal, step, nb, s); break;
-        case 4: patch_dispatch<T, 4>(A, x, y, part, scal, step, nb, s); break;
-        case 5: patch_dispatch<T, 5>(A, x, y, part, scal, step, nb, s); break;
-        case 6: patch_dispatch<T, 6>(A, x, y, part, scal, step, nb, s); break;
-        case 7: patch_dispatch<T, 7>(A, x, y, part, scal, step, nb, s); break;
-        default: patch_dispatch<T, 8>(A, x, y, part, scal, step, nb, s); break;
+        case 1: patch_dispatch<T, 1>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 2: patch_dispatch<T, 2>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 3: patch_dispatch<T, 3>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 4: patch_dispatch<T, 4>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 5: patch_dispatch<T, 5>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 6: patch_dispatch<T, 6>(A, x, y, part, scal, step, nb, s, defer); break;
+        case 7: patch_dispatch<T, 7>(A, x, y, part, scal, step, nb, s, defer); break;
+        default: patch_dispatch<T, 8>(A, x, y, part, scal, step, nb, s, defer); break;
     }
 }
-template void launch_patch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int);
-template void launch_patch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int);
+template void launch_patch_spmm<double>(const CsrViewT<double> &, int, const double *, double *, double *, const double *, int, hipStream_t, int, bool);
+template void launch_patch_spmm<float>(const CsrViewT<float> &, int, const float *, float *, double *, const double *, int, hipStream_t, int, bool);
 
 }  // namespace remo

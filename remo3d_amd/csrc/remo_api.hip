@@ -146,8 +146,11 @@ int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row le
 int g_amg32 = 1;     // key 17: 1 = fp64 solves run the multigrid cycle in fp32 storage (default), 0 = in fp64
 int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
+inline bool g_auto_patch_ok(int op);
+int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
 int g_auto_patch = 1; // key 20: 1 = op 0 takes the patch operator in 3D whenever its tables fit (default), 0 = the round-2 choice by size
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
+inline bool g_auto_patch_ok(int op) { return op == 3 || g_auto_patch != 0; }
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
 // fp64 side of a mixed-precision inner solve: where the residual replacements read and write
@@ -183,11 +186,11 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
         // time_kernels = k: every k-th SpMM launch is bracketed with events (a bracket costs the stream ~1.5 us)
         if (time_kernels > 0 && (step % time_kernels) == (time_kernels / 2) && ev_used + 2 <= ctx->spmv_ev.size()) {
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used], s));
-            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step, buf.defer_q);
             HIP_TRY(hipEventRecord(ctx->spmv_ev[ev_used + 1], s));
             ev_used += 2;
         } else {
-            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step);
+            launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step, buf.defer_q);
         }
         bool replaced = false;
         if constexpr (std::is_same<T, float>::value) {
@@ -543,10 +546,14 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // ---- dof numbering + CSR pattern (device) ------------------------------------------
         std::string err;
         DeviceSymbolic &sy = b->sym;
-        int rc = build_symbolic_gpu(ctx->ar, s, dim, nv, nt, b->d_conn, b->nbf, b->d_bconn, b->d_bdir, o.condense != 0, ctx->d_err, sy, err);
+        // patch operator batches above 200 k tetrahedra (assemble = 2: any size) number only the P1 block of the matrix
+        const bool want_patch0 = dim == 3 && (o.op == 3 || o.op == 0) && g_auto_patch_ok(o.op);
+        const int64_t vertex_block_above = (want_patch0 && o.assemble != 1) ? (o.assemble == 2 ? 0 : 200000) : -1;
+        int rc = build_symbolic_gpu(ctx->ar, s, dim, nv, nt, b->d_conn, b->nbf, b->d_bconn, b->d_bdir, o.condense != 0, ctx->d_err, sy, err, vertex_block_above);
         if (rc != REMO_OK) return fail(ctx, rc, err);
         st->ms_symbolic = now_ms() - t_start;
-        st->n_dof = sy.ndof; st->n_free = sy.nfree; st->nnz = sy.nnz; st->n_edges = sy.ne; st->n_faces = sy.nf;
+        const bool lite = sy.vertex_block_only;     // only the P1 block has a pattern: the operator is the patch operator
+        st->n_dof = sy.ndof; st->n_free = sy.nfree; st->nnz = lite ? 0 : sy.nnz; st->n_edges = sy.ne; st->n_faces = sy.nf;
         st->n_rhs = b->n_rhs;
         const int64_t n = sy.nfree;
 
@@ -612,6 +619,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         launch_metric_terms(dim, nt, b->d_coords, sy.conn, b->d_mat, sy.eperm, b->d_sigma, b->n_mat, d_C, ctx->d_err, s);
         int64_t pair_begin = 0, pair_end = 0;   // edge-dof rows: consecutive pairs with identical patterns, values interleaved
         if (sy.nvefree > sy.nvfree && ((sy.nvefree - sy.nvfree) & 1) == 0) { pair_begin = sy.nvfree; pair_end = sy.nvefree; }
+        if (lite) {   // values of the P1 block (the generic row walk over the vertex rows: their columns are vertex dofs, other local dofs
+                      // of an element fall behind the row's last column and are dropped) + the Jacobi factors of every other row
+            pair_begin = pair_end = 0;
+            launch_assemble(dim, sy.condense, sy.nvfree, 0, 0, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
+            launch_diag_rows(dim, sy.nvfree, n, sy.adjptr, sy.adj, d_C, d_M, d_dinv, s);
+        } else
         launch_assemble(dim, sy.condense, n, pair_begin, pair_end, sy.rowptr, sy.col, sy.adjptr, sy.adj, sy.eldof, d_C, d_M, d_val, d_dinv, s);
         HIP_TRY(hipEventRecord(ctx->ev[2], s));
 
@@ -636,7 +649,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const bool want_square = two_level && !want_amg && (buf.cheb_degree % 2 == 0) && ((g_square == 1 && dim == 2) || g_square == 2);
         // measured in the bench (--tune 13=0 against 13=1, one box): 538.9 -> 516.1 ms solve per step at 83 k vertices; at 12.8 k the
         // launches are latency, not bytes (714 -> 710 ms) and building the copy costs what it saves: larger blocks only (2 forces it)
-        const bool want_compact = two_level && !want_square && (g_compact == 2 || (g_compact == 1 && buf.nv_coarse > 16384));
+        const bool want_compact = !lite && two_level && !want_square && (g_compact == 2 || (g_compact == 1 && buf.nv_coarse > 16384));
         if (two_level) {  // spectrum bound of the Jacobi-scaled vertex block for the Chebyshev interval
             HIP_TRY(hipMemsetAsync(d_bound, 0, sizeof(unsigned long long), s));
             launch_vblock_bound(buf.nv_coarse, CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val}, d_dinv, d_bound, s);
@@ -676,6 +689,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         HIP_TRY(hipMemcpyAsync(&h_err, ctx->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (want_compact && h_vb[0] == 0 && h_vb[1] > 0) { buf.vb_rowptr = vb_rowptr; buf.vb_col = vb_col; buf.vb_val = vb_val; }
+        if (lite && two_level) { buf.vb_rowptr = sy.rowptr; buf.vb_col = sy.col; buf.vb_val = d_val; h_vb[0] = 0; h_vb[1] = int32_t(sy.nnz); }   // the assembled block IS the compact vertex block
         // fp32 Chebyshev chain inside the fp64 solve (remo_debug_tune key 15: 0 = off): where the chain's launches are HBM streams
         // (no folded first step: more than 32 k vertex rows) and the compact block exists
         if (g_chain32 && o.precision == 0 && buf.vb_rowptr && (buf.nv_coarse > 32768 || g_chain32 == 2)) {   // 2: forced (tests)
@@ -715,6 +729,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
 
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
+        b->A.vertex_block_only = lite;
         // measured (bench, fp64, k = 5): 13.7 M stored entries CSR 49 us / element-wise 61; 21.6 M 102 / 78; 32.8 M 148 / 109; 93 M 472 / 381
         // (its buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
         const bool elem_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
@@ -722,8 +737,9 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
         const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24);
+        if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
-        const bool patch_op = patch_ok && (o.op == 3 || (o.op == 0 && g_auto_patch));
+        const bool patch_op = patch_ok && (lite || o.op == 3 || (o.op == 0 && g_auto_patch));
         const bool elem_op = !patch_op && dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
         st->op_used = patch_op ? 3 : (elem_op ? 1 : 0);
         if (patch_op) {
@@ -752,6 +768,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int lpr = choose_lanes_per_row(n, sy.nnz);
         buf.nb_spmv = spmv_grid(n, lpr);
         buf.nb_vec = vec_grid(n);
+        buf.defer_q = patch_op && g_defer_q && !pcg_update_folds(buf);     // the update launch sums the shared rows of q = A p itself
         const bool mixed = (o.precision == 1);
         MixedBuffers mx;
         if (mixed) {   // fp32 images of the system for the inner solver
@@ -760,7 +777,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             launch_to_float(sy.nnz, d_val, v32, s);
             launch_to_float(n, d_dinv, dinv32, s);
             mx.A32 = CsrViewT<float>{n, sy.nnz, sy.rowptr, sy.col, v32};
-            mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end;
+            mx.A32.pair_begin = b->A.pair_begin; mx.A32.pair_end = b->A.pair_end; mx.A32.vertex_block_only = lite;
             if (patch_op) {   // the slab and the partial sums are scratch of one application: the fp32 operator shares them
                 b->patch32 = PatchOpT<float>{ptab, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, h_patch[1]};
                 mx.A32.patch = &b->patch32;
@@ -793,6 +810,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
                 f.sq_rowptr = buf.sq_rowptr; f.sq_col = buf.sq_col; f.sq_a = a32; f.sq_b = b32; f.sq_lanes = buf.sq_lanes;
             }
         }
+        if (mixed) mx.b32.defer_q = patch_op && g_defer_q && !pcg_update_folds(mx.b32);
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
         size_t ev_used = 0;
@@ -941,6 +959,8 @@ int remo_batch_get_system(remo_ctx_t *ctx, remo_batch_t *b, int32_t *rowptr, int
                           int32_t *freeid) {
     if (!ctx) return REMO_ERR_ARG;
     if (!b || !b->has_system || b->run_id != ctx->run_id) return fail(ctx, REMO_ERR_ARG, "no assembled system on this batch (run it first)");
+    if (b->A.vertex_block_only && (rowptr || col || val))
+        return fail(ctx, REMO_ERR_ARG, "the last run assembled only the diagonal and the P1 block (remo_opts_t.assemble): run with assemble = 1 to inspect the matrix");
     try {
         HIP_TRY(hipSetDevice(ctx->device));
         const DeviceSymbolic &sy = b->sym;
@@ -1202,6 +1222,8 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     if (!ctx) return REMO_ERR_ARG;
     if (!b || !b->has_system || b->run_id != ctx->run_id || !x || !y || k < 1 || k > REMO_MAX_RHS || reps < 1)
         return fail(ctx, REMO_ERR_ARG, "bad argument");
+    if (b->A.vertex_block_only && !patch_applies(b->A, k))
+        return fail(ctx, REMO_ERR_ARG, "the last run assembled no matrix and its patch tables hold fewer columns than asked for (remo_opts_t.assemble = 1 keeps the matrix)");
     double *dx = nullptr, *dy = nullptr;
     try {
         HIP_TRY(hipSetDevice(ctx->device));
@@ -1232,7 +1254,7 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, double *out16) {
     if (!ctx || !b || !out16) return REMO_ERR_ARG;
     if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");
     const int k = 5;
-    if (k * b->patch64.t.E > 256) return fail(ctx, REMO_ERR_ARG, "the batch's patch tables are laid out for fewer than 5 columns");
+    if (k * b->patch64.t.E > b->patch64.t.block) return fail(ctx, REMO_ERR_ARG, "the batch's patch tables are laid out for fewer than 5 columns");
     double *dx = nullptr, *dy = nullptr;
     long long *st = nullptr;
     try {
@@ -1282,8 +1304,10 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 7) g_sq_lanes = value;
     else if (key == 8) set_symbolic_tuning(value);
     else if (key == 18) set_element_order(value);
+    else if (key == 19) set_patch_block(value);
     else if (key == 20) g_auto_patch = value;
     else if (key == 21) set_patch_mode(value);
+    else if (key == 22) g_defer_q = value;
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

@@ -44,7 +44,8 @@ struct DeviceSymbolic {
     int32_t *eperm = nullptr;   // [nt] input element of element t (nullptr: input order kept)
     int32_t *eldof = nullptr;   // [nt][nld_full] free row or -1
     int32_t *freeid = nullptr;  // [ndof]
-    int32_t *rowptr = nullptr;  // [nfree+1]
+    bool vertex_block_only = false;   // rowptr / col / nnz describe only the leading nvfree x nvfree (P1) block: the caller applies A matrix-free
+    int32_t *rowptr = nullptr;  // [nfree+1] (vertex_block_only: [nvfree+1] valid)
     int32_t *col = nullptr;     // [nnz]
     int32_t *adjptr = nullptr;  // [nfree+1]
     uint32_t *adj = nullptr;    // element << 5 | local dof, ascending per row
@@ -55,7 +56,7 @@ size_t symbolic_gpu_arena_bytes(int dim, int64_t nv, int64_t nt, int64_t nbf);
 // All device work is enqueued on `s`; the function synchronises three times to read sizes back.
 int build_symbolic_gpu(Arena &ar, hipStream_t s, int dim, int64_t nv, int64_t nt, const int32_t *d_conn_in, int64_t nbf,
                        const int32_t *d_bconn, const uint8_t *d_bdir, bool condense, int32_t *d_err, DeviceSymbolic &out,
-                       std::string &err);
+                       std::string &err, int64_t vertex_block_above = -1);   // >= 0: 3D meshes with more elements get the pattern of the P1 block only
 
 // probe hook: 0 = build the CSR pattern by the global sort instead of row by row
 void set_symbolic_tuning(int row_pattern);

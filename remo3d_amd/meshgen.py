@@ -307,6 +307,18 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
         proj = np.concatenate([proj, np.ones(n_iface, bool)])          # interface points are pinned like boundary points
         on_axis = np.concatenate([on_axis, ip[:, 0] == 0.0])
 
+    # Coincident points: lattice points pulled onto the sphere can land on the same spot (the poles and the equator points of the
+    # half ball: two lattice points on one ray).  Qhull takes minutes over an exact duplicate that happens to be a hull point,
+    # seconds otherwise - a sweep of 40 batches met three such meshes.  Of a coincident pair the later point goes, unless it is
+    # an interface point (those come last and are pinned).
+    pairs = cKDTree(pts).query_pairs(1e-9 * R, output_type="ndarray")
+    if len(pairs):
+        first_iface = len(pts) - n_iface
+        lose = np.where(pairs[:, 1] >= first_iface, pairs[:, 0], pairs[:, 1])
+        lose = lose[lose < first_iface]
+        keep_p = np.ones(len(pts), bool)
+        keep_p[lose] = False
+        pts, hs, proj, on_axis = pts[keep_p], hs[keep_p], proj[keep_p], on_axis[keep_p]
     is_iface = np.zeros(len(pts), bool)
     if n_iface:
         is_iface[len(pts) - n_iface:] = True

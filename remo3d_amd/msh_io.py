@@ -25,7 +25,30 @@ _NODES = {1: 2, 2: 3, 4: 4, 15: 1}
 _DIM = {1: 1, 2: 2, 4: 3, 15: 0}
 
 
-def read_msh(path: str, dim: int, dirichlet_name: str = "dirichlet_boundary") -> Mesh:
+def morton_renumber(mesh: Mesh) -> Mesh:
+    """The same mesh with its nodes renumbered along a Morton curve (21 bits per coordinate).  The device path numbers edge / face
+    dofs by their vertices and cuts the (vertex-sorted) element list into patches, so its vectors and patches are compact when
+    neighbouring vertices have neighbouring numbers; the in-repo meshers deliver that, a Gmsh file need not.  Potentials do not
+    depend on the numbering."""
+    pts = mesh.coords
+    q = np.floor((pts - pts.min(0)) / (pts.max(0) - pts.min(0) + 1e-300) * ((1 << 21) - 1)).astype(np.uint64)
+    key = np.zeros(len(pts), dtype=np.uint64)
+    for bit in range(21):
+        for k in range(mesh.dim):
+            key |= ((q[:, k] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(bit * mesh.dim + k)
+    order = np.argsort(key, kind="stable")
+    new_id = np.empty(len(pts), dtype=np.int64)
+    new_id[order] = np.arange(len(pts))
+    meta = dict(mesh.meta)
+    for name in ("node_h", "node_iface"):       # per-node arrays of the in-repo meshers follow the nodes
+        if name in meta and hasattr(meta[name], "__len__") and len(meta[name]) == len(pts):
+            meta[name] = np.asarray(meta[name])[order]
+    return Mesh(mesh.dim, np.ascontiguousarray(pts[order]), np.ascontiguousarray(new_id[mesh.conn].astype(np.int32)), mesh.mat,
+                np.ascontiguousarray(new_id[mesh.bconn].astype(np.int32)) if len(mesh.bconn) else mesh.bconn, mesh.bdirichlet, meta)
+
+
+def read_msh(path: str, dim: int, dirichlet_name: str = "dirichlet_boundary", renumber: bool = False) -> Mesh:
+    """renumber = True: nodes in Morton order (morton_renumber) instead of file order - what a mesh on its way to the GPU wants."""
     with open(path) as f:
         lines = f.read().split("\n")
     i = 0
@@ -86,8 +109,9 @@ def read_msh(path: str, dim: int, dirichlet_name: str = "dirichlet_boundary") ->
     else:
         bconn = np.zeros((0, dim), dtype=np.int32); bdir = np.zeros(0, dtype=np.uint8)
     xyz = np.asarray(coords, dtype=np.float64)[:, :dim]
-    return Mesh(dim, np.ascontiguousarray(xyz), np.ascontiguousarray(conn), mat, np.ascontiguousarray(bconn), bdir,
+    mesh = Mesh(dim, np.ascontiguousarray(xyz), np.ascontiguousarray(conn), mat, np.ascontiguousarray(bconn), bdir,
                 dict(physical_names=names, elementary_tags=list(first.keys())))
+    return morton_renumber(mesh) if renumber else mesh
 
 
 def write_msh(path: str, mesh: Mesh, elementary_tags: Optional[Sequence[int]] = None) -> None:

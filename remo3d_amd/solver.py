@@ -25,7 +25,7 @@ class RemoError(RuntimeError):
 
 def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-8, check_every=5,
               time_kernels=False, coarse_degree=0, coarse_ratio=0, precision="fp64", inner_digits=0,
-              serialize_solves=False, op="auto", coarse="auto", quadrature="exact") -> RemoOpts:
+              serialize_solves=False, op="auto", coarse="auto", quadrature="exact", assemble="auto") -> RemoOpts:
     """Options with the reference's names (remo3d.py:82-83, ngsolve_functions.py:46, 50).
     precision: "fp64" (default) or "mixed" = PCG in fp32 storage inside an fp64 residual-refinement loop
     (BASELINE config 5); inner_digits: decimal digits of <Cr,r> between two residual replacements (0 = library default 3)."""
@@ -56,6 +56,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     if quadrature not in ("exact", "degree4"):
         raise ValueError("quadrature must be 'exact' or 'degree4' (2D reference tensors by the 6-point rule)")
     o.quadrature = 1 if quadrature == "degree4" else 0
+    if assemble not in ("auto", "full", "vertex_block"):
+        raise ValueError("assemble must be 'auto', 'full' or 'vertex_block' (diagonal + P1 block only: patch operator batches)")
+    o.assemble = {"auto": 0, "full": 1, "vertex_block": 2}[assemble]
     return o
 
 

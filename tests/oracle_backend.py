@@ -23,3 +23,30 @@ class OracleContext:
 
     def close(self):
         pass
+
+
+class OracleDirectContext(OracleContext):
+    """The oracle's SYSTEMS (numbering, quadrature assembly, condensed bubble, point sources, evaluation - oracle/fem_oracle.c)
+    with the linear solve done by a sparse direct factorisation (SuperLU through scipy, symmetric mode) instead of the oracle's
+    Jacobi-PCG: the same right-hand sides solved to rounding, ~10 x faster at the default 2D mesh scale (one factorisation per
+    batch serves its 5-10 right-hand sides; the PCG needs ~2300 steps each).  Used where the subject of the test is everything
+    AROUND the iteration - meshes, windowing, assembly, sources, evaluation, Ra - against the reference's logs; the oracle's PCG
+    itself is pinned by the GPU-vs-oracle tests and by the PCG-backed sweep of test_oracle_reference_logs.py."""
+
+    def solve_batch(self, mesh, sigma, sources, evals, opts, raise_on_error=True):
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        from oracle.fem_oracle import Oracle
+        o = Oracle(mesh, sigma, condense=bool(opts.condense))
+        try:
+            rp, col, val = o.csr()
+            lu = spla.splu(sp.csr_matrix((val, col, rp), shape=(o.nfree, o.nfree)).tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
+                           options=dict(SymmetricMode=True))
+            outs = []
+            for (z, I), e in zip(sources, evals):
+                f, se, sf = o.rhs(list(z), list(I))
+                outs.append(np.asarray(o.eval(lu.solve(f), list(e), (se, sf))))
+            self.calls += 1
+            return outs, dict(pcg_steps=0, n_free=o.nfree), 0
+        finally:
+            o.close()

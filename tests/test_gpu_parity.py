@@ -574,6 +574,73 @@ def test_patch_operator_solves_like_the_csr_path(precision, pre, mesh3d, gpu_ctx
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_patch_operator_with_the_shared_rows_summed_by_the_update_launch(precision, mesh3d, gpu_ctx):
+    """Inside the PCG the patch operator leaves the rows shared by several patches in its boundary slab and the update launch
+    sums them while it reads q (no k_patch_reduce launch; remo_debug_tune 22 = 0 restores it).  Large meshes run that way by
+    default; the small test mesh does once the first Chebyshev step is kept out of the update launch (key 9 = 0), which would
+    gather q.  Same potentials as the CSR path, same step counts, true residual of the returned solution."""
+    from remo3d_amd import _lib, solver
+    L = _lib.load()
+    ref, st0, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-11, maxsteps=5000, precision=precision, op="csr"))
+    assert rc == 0
+    L.remo_debug_tune(9, 0)
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        steps = {}
+        for defer in (1, 0):
+            L.remo_debug_tune(22, defer)
+            assert b.run(solver.make_opts(rtol=1e-11, maxsteps=5000, precision=precision, op="patch")) == 0
+            assert b.stats["op_used"] == 3
+            steps[defer] = b.stats["pcg_steps"]
+            for u, v in zip(b.fetch(), ref):
+                assert np.allclose(u, v, rtol=1e-8, atol=0)
+            assert np.max(b.true_relres()) < 5e-11
+        assert abs(steps[0] - steps[1]) <= max(3, steps[0] // 20), steps
+    finally:
+        L.remo_debug_tune(9, 1); L.remo_debug_tune(22, 1)
+        b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+@pytest.mark.parametrize("pre", ["local", "multigrid"])
+def test_patch_operator_without_the_assembled_matrix(precision, pre, mesh3d, gpu_ctx):
+    """remo_opts_t.assemble = 2 (what batches above 200 k tetrahedra do by default): only the Jacobi diagonal and the P1 block
+    the preconditioner solves are assembled, the CG never reads stored entries.  Same potentials and step counts as with the
+    whole matrix; the diagonal is the assembled one; the matrix inspection hook says why it has nothing to show; also with the
+    multigrid cycle on the P1 block."""
+    from oracle.fem_oracle import Oracle
+    from remo3d_amd import solver
+    ref, st0, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-11, maxsteps=5000, precision=precision, op="patch", assemble="full"))
+    assert rc == 0 and st0["nnz"] > 0
+    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC, EVAL)
+    try:
+        for coarse in (("auto", "amg") if pre == "multigrid" else ("auto",)):
+            assert b.run(solver.make_opts(preconditioner=pre, rtol=1e-11, maxsteps=5000, precision=precision, op="patch", assemble="vertex_block", coarse=coarse)) == 0
+            assert b.stats["op_used"] == 3 and b.stats["nnz"] == 0
+            for u, v in zip(b.fetch(), ref):
+                assert np.allclose(u, v, rtol=1e-8, atol=0)
+            if coarse == "auto":
+                assert abs(b.stats["pcg_steps"] - st0["pcg_steps"]) <= max(3, st0["pcg_steps"] // 20)
+        o = Oracle(mesh3d, SIGMA3, condense=True)
+        rp, col, val = o.csr()
+        diag = np.array([val[rp[i]:rp[i + 1]][col[rp[i]:rp[i + 1]] == i][0] for i in range(0, o.nfree, 97)])
+        assert np.allclose(1.0 / b.jacobi()[::97], diag, rtol=1e-12)
+        x = np.random.default_rng(0).standard_normal((o.nfree, 3))
+        y, _ = b.spmv(x)
+        yr = np.stack([o.spmv(x[:, c]) for c in range(3)], 1)
+        assert np.max(np.abs(y - yr)) <= 5e-12 * np.max(np.abs(yr))
+        with pytest.raises(solver.RemoError) as e:
+            b.system()
+        assert "assemble" in str(e.value)
+        with pytest.raises(solver.RemoError):
+            b.spmv(np.zeros((o.nfree, 8)))          # more columns than the batch's tables hold, and no matrix to fall back on
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
 def test_patch_operator_without_element_locality(mesh3d, gpu_ctx):
     """The library orders the elements itself (by their smallest vertices): a mesh handed over with shuffled elements gives
     the same potentials through the patch operator, and so does the shuffled list taken as it comes (remo_debug_tune 18 = 0:

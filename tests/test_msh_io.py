@@ -86,3 +86,25 @@ def test_round_trip_preserves_the_linear_system(mesh2d, tmp_path):
     u0, rc0, _ = solve_batch(mesh2d, SIGMA3, *args, rtol=1e-12)
     u1, rc1, _ = solve_batch(back, sigma_back, *args, rtol=1e-12)
     assert rc0 == 0 and rc1 == 0 and np.allclose(u0, u1, rtol=1e-9)
+
+
+def test_morton_renumbering_keeps_the_mesh(tmp_path):
+    """read_msh(renumber=True): the same elements on renumbered nodes - coordinates of every element, materials and Dirichlet
+    facets unchanged; neighbouring vertices get neighbouring numbers (the locality the device path's patches live on)."""
+    from remo3d_amd import msh_io
+    from remo3d_amd.meshgen import make_mesh
+    mesh = make_mesh(3, 50.0, [0.0], scale=10.0, seed=0)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(mesh.n_nodes)                       # a file whose node order carries no locality
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    import copy
+    sh = copy.copy(mesh)
+    sh.coords = np.ascontiguousarray(mesh.coords[perm]); sh.conn = inv[mesh.conn].astype(np.int32); sh.bconn = inv[mesh.bconn].astype(np.int32)
+    p = str(tmp_path / "shuffled.msh")
+    msh_io.write_msh(p, sh)
+    plain, back = msh_io.read_msh(p, 3), msh_io.read_msh(p, 3, renumber=True)
+    assert np.array_equal(np.sort(back.coords[back.conn].sum(2), axis=1), np.sort(plain.coords[plain.conn].sum(2), axis=1))
+    assert np.allclose(back.coords[back.conn].mean(1), plain.coords[plain.conn].mean(1)) and np.array_equal(back.mat, plain.mat)
+    assert np.allclose(back.coords[back.bconn].mean(1), plain.coords[plain.bconn].mean(1)) and np.array_equal(back.bdirichlet, plain.bdirichlet)
+    spread = lambda m: np.median(np.ptp(np.sort(m.conn, axis=1), axis=1))
+    assert spread(back) < 0.2 * spread(plain), (spread(back), spread(plain))

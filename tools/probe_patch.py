@@ -10,9 +10,12 @@ import bench
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = None
+    coarse = "auto"
     for a in sys.argv[1:]:
         if a.startswith("--ops="):
             only = a[6:].split(",")
+        if a.startswith("--coarse="):
+            coarse = a[9:]
     sizes = args or ["S"]
     work = {}
     for sz in sizes:
@@ -35,7 +38,7 @@ def main():
                 if mode and not only:
                     continue
                 L.remo_debug_tune(21, 0)
-                rc = b.run(solver.make_opts(rtol=1e-8, op=op), raise_on_error=False)
+                rc = b.run(solver.make_opts(rtol=1e-8, op=op, coarse=coarse), raise_on_error=False)
                 st = dict(b.stats)
                 n = st["n_free"]
                 x = np.random.default_rng(0).standard_normal((n, 5))

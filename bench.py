@@ -257,14 +257,17 @@ def box_stream(device):
 
 
 def pmc_traffic(workload, n_free, nnz, op="csr"):
-    """HBM bytes per operator application from the committed rocprofv3 --pmc passes of this exact workload
-    (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py); None when the run differs."""
+    """HBM bytes per operator application from the committed rocprofv3 --pmc passes of this workload's mesh size and operator
+    (profiles/, collected with tools/collect_traffic.sh + tools/pmc_traffic.py on the first 20 depths of the sweep: the profiled
+    run meshes in-process); None when size or operator differ."""
+    import re
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             p = json.load(f)
     except OSError:
         return None
-    if p.get("workload") == workload and p.get("n_free") == n_free and p.get("nnz") == nnz and p.get("operator", "csr") == op:
+    size = re.search(r"mesh size (\w+)", workload or "")
+    if size and p.get("mesh_size") == size.group(1) and p.get("operator", "csr") == op:
         return p["spmm"]["traffic_bytes_per_launch"]
     return None
 
@@ -308,8 +311,11 @@ class Runner:
         self.np, self.sweep, self.tasks = np, sweep, tasks
         self.work, self.n_depths, self.opts, self.schedule = work, n_depths, opts, schedule
         self.ctxs = [solver.Context(local) for _ in range(max(1, streams))]
-        self.resident = [self.ctxs[i % len(self.ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
-        self.all_resident = all_resident          # dynamic schedule: every rank holds every batch, the queue index is the batch index
+        # dynamic schedule (all_resident: the rank holds the host data of every batch, the queue index is the batch index): nothing
+        # is uploaded ahead - a drawn batch is brought in by an uploader context on its own stream while the one before it runs
+        self.all_resident = all_resident
+        self.uploader = solver.Context(local) if all_resident else None
+        self.resident = [] if all_resident else [self.ctxs[i % len(self.ctxs)].batch(w["mesh"], w["sigma"], w["sources"], w["evals"]) for i, w in enumerate(work)]
         self.pool = None
         if len(self.ctxs) > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -318,12 +324,13 @@ class Runner:
     def close(self):
         for b in self.resident:
             b.close()
-        for c in self.ctxs:
+        for c in self.ctxs + ([self.uploader] if self.uploader else []):
             c.close()
 
-    def _collect(self, i, rc, slab, agg):
+    def _collect(self, i, rc, slab, agg, b=None):
         np = self.np
-        w, b = self.work[i], self.resident[i]
+        w = self.work[i]
+        b = self.resident[i] if b is None else b
         st = b.stats
         if rc < 0:
             for rd in w["readers"]:
@@ -361,9 +368,25 @@ class Runner:
                 return [(i, self.resident[i].run(self.opts, raise_on_error=False)) for i in range(j, len(self.resident), len(self.ctxs))]
             for i, rc in sorted(p for chunk in self.pool.map(drive, range(len(self.ctxs))) for p in chunk):
                 self._collect(i, rc, slab, agg)
+        elif self.all_resident:      # pull scheduling: draw, upload (one batch ahead, on the uploader's stream), run, release
+            from concurrent.futures import ThreadPoolExecutor
+            queue = iter(self.sweep.BatchQueue(len(self.work), self.schedule))
+
+            def bring(i):
+                w = self.work[i]
+                return self.uploader.batch(w["mesh"], w["sigma"], w["sources"], w["evals"])
+            with ThreadPoolExecutor(max_workers=1) as up:
+                i = next(queue, None)
+                fut = up.submit(bring, i) if i is not None else None
+                while fut is not None:
+                    cur_i, cur = i, fut.result()
+                    i = next(queue, None)            # a drawn batch is OWNED: one ahead, no more (the other ranks may be idle for it)
+                    fut = up.submit(bring, i) if i is not None else None
+                    self._collect(cur_i, cur.run(self.opts, raise_on_error=False, ctx=self.ctxs[0]), slab, agg, b=cur)
+                    self.last_fetch = cur.fetch() if cur_i == 0 else getattr(self, "last_fetch", None)
+                    cur.close()
         else:
-            queue = self.sweep.BatchQueue(len(self.work), self.schedule) if self.all_resident else range(len(self.work))
-            for i in queue:
+            for i in range(len(self.work)):
                 self._collect(i, self.resident[i].run(self.opts, raise_on_error=False), slab, agg)
         agg["busy_s"] = time.time() - t_busy
         slab = self.sweep.combine(slab)   # the ONE collective of the path: all-reduce of the log slab
@@ -436,7 +459,7 @@ def main():
                     help="strong scaling: this many depths in all, shared by the ranks (BASELINE configs[3]: 1000)")
     ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
                     help="static = block-cyclic shares; dynamic = ranks draw batches from a shared counter while they are free "
-                         "(the reference's pull scheduling); every rank then keeps every batch resident")
+                         "(the reference's pull scheduling); a drawn batch is uploaded by a second context while the one before it runs")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxsteps", type=int, default=1000)
     ap.add_argument("--mesh", default="lattice", choices=["lattice", "conforming"],
@@ -500,10 +523,16 @@ def main():
     profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB"))
     if profiled:
         log("running under a profiler: meshes are built in this process (no child processes behind a preloaded tool library)")
-    if args.mesh_workers > 1 and world == 1 and not profiled:
+    # every rank builds the meshes of its own batches in its own CPU-only worker processes (N ranks share the node's cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 8
+    n_workers = args.mesh_workers if world == 1 else max(2, min(args.mesh_workers, cores // world))
+    if n_workers > 1 and not profiled:
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
-        mesh_pool = ProcessPoolExecutor(max_workers=args.mesh_workers, mp_context=multiprocessing.get_context("spawn"))
+        mesh_pool = ProcessPoolExecutor(max_workers=n_workers, mp_context=multiprocessing.get_context("spawn"))
     t_mesh0 = time.time()
     if mesh_pool is not None:
         os.environ.setdefault("OMP_NUM_THREADS", "1")      # inherited by the spawned mesh workers: one thread each
@@ -635,7 +664,7 @@ def main():
         out["value_h2d_inclusive"] = dict(value=n_points * max(1, min(args.steps, 2)) / dth, unit="points/s",
                                           note="remo_solve_batch per batch: upload of the mesh arrays (pageable host memory) + run + fetch inside the timed span",
                                           max_abs_log_diff_vs_resident=float(np.nanmax(np.abs(slab_h - slab))))
-    got0 = runner.resident[0].fetch()[0].copy()
+    got0 = runner.resident[0].fetch()[0].copy() if runner.resident else None
     runner.close()
     if extras:
         out["box"] = box_stream(local)
@@ -666,7 +695,7 @@ def main():
         cb, ref_out = cpu_baseline_finish(cpu_leg)
         log("CPU baseline leg done")
         out["cpu_baseline"] = cb
-        if ref_out is not None:
+        if ref_out is not None and got0 is not None:
             out["config"]["gpu_vs_oracle_max_rel_diff_batch0_rhs0"] = float(np.max(np.abs(got0 - ref_out) / np.abs(ref_out)))
     print(json.dumps(out))
 

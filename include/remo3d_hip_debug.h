@@ -32,7 +32,7 @@ int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
  * boundaries of k_patch_apply averaged over the workgroups of one launch - out16[0..6] = row tables into LDS | staging of x | x into registers |
  * zeroing | tensor arithmetic + LDS accumulation | output | partial sums; [7] whole workgroup; [8] first start to last end of the
  * launch; [9] workgroups.  The last run on the batch must have used the patch operator. */
-int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *batch, double *out16);
+int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *batch, int32_t fp32 /* the fp32 instantiation instead */, double *out16);
 
 /* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
  * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of

@@ -94,7 +94,7 @@ def load():
     L.remo_batch_apply_coarse.restype = C.c_int
     L.remo_batch_apply_coarse.argtypes = [vp, vp, C.c_int32, dp, dp, C.c_int32, i64p]
     L.remo_debug_patch_phases.restype = C.c_int
-    L.remo_debug_patch_phases.argtypes = [vp, vp, dp]
+    L.remo_debug_patch_phases.argtypes = [vp, vp, C.c_int32, dp]
     L.remo_debug_xcc.restype = C.c_int
     L.remo_debug_xcc.argtypes = [vp, ip, C.c_int32]
     L.remo_debug_cache_gather.restype = C.c_int

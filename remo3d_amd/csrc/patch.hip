@@ -33,6 +33,7 @@ namespace remo {
 
 namespace {
 
+constexpr int kPatchDotBlocks = 32;                    // workgroups of k_patch_dot
 constexpr int kPatchPasses = 12;                       // k_patch_apply: loads a lane keeps in flight
 constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192 (E <= 256: patch_elements_per_group)
 constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
@@ -204,8 +205,8 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
     constexpr uint32_t S = sizeof(T);
     const int rows_pad = (rows + U * EK - 1) / (U * EK) * (U * EK);
     extern __shared__ double lds_raw[];
-    T *xs = reinterpret_cast<T *>(lds_raw);              // [(rows + 2)][K]: x rows, later the accumulators of y; row `rows` = zeros, row rows + 1 = slack
-    int32_t *trow = reinterpret_cast<int32_t *>(lds_raw + ((size_t(rows + 2) * K * sizeof(T) + 7) >> 3));   // [rows_pad] matrix row of local row m
+    T *xs = reinterpret_cast<T *>(lds_raw);              // [(rows + 2)][K]: x rows (T), later the accumulators of y (double); row `rows` = zeros, row rows + 1 = slack
+    int32_t *trow = reinterpret_cast<int32_t *>(lds_raw + size_t(rows + 2) * K);   // [rows_pad] matrix row of local row m (behind rows + 2 rows of K doubles)
     int32_t *tout = trow + rows_pad;                     // [rows_pad] -1 or slab slot
     __shared__ double smem[16 * K];
     const int tid = threadIdx.x;
@@ -285,7 +286,10 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
     }
     __syncthreads();        // every lane holds its x values: the staging area becomes the accumulators
     REMO_STAMP(3)
-    for (int j = tid; j < (rows + 1) * K; j += BLK) xs[j] = T(0);
+    // the accumulators are fp64 whatever T is: ds_add_f32 runs at about a lane per clock on this chip (measured: 204 of the 304 us
+    // of the fp32 kernel at 443 k tetrahedra were its 20 atomics per lane; ds_add_f64 costs 4 us there)
+    double *ya = lds_raw;
+    for (int j = tid; j < (rows + 1) * K; j += BLK) ya[j] = 0.0;
     __syncthreads();
     REMO_STAMP(4)
     double d0 = 0.0;
@@ -318,8 +322,8 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            if constexpr (MODE == 1) xs[l * K + c0] = yv[i];
-            else lds_add(xs + l * K + c0, yv[i]);
+            if constexpr (MODE == 1) ya[l * K + c0] = double(yv[i]);
+            else lds_add(ya + l * K + c0, double(yv[i]));
         }
     }
     __syncthreads();
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
             for (int u = 0; u < U; ++u) {
                 const int m = m0 + el + EK * u;
                 r[u] = trow[m] | off_mask; o[u] = tout[m];
-                v[u][0] = xs[m * K + c0];       // (behind the staged rows: whatever LDS holds, never stored)
+                v[u][0] = T(ya[m * K + c0]);    // (behind the staged rows: whatever LDS holds, never stored)
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {       // one of the two stores of a value is out of range: dropped by the hardware, no branch
@@ -490,11 +494,11 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     auto launch = [&](auto kernel, int blk) {
         const int pass = kPatchPasses * (blk / K);
         const size_t rows_pad = size_t((P.lds_rows + pass - 1) / pass) * pass;
-        const size_t bytes = ((size_t(P.lds_rows + 2) * K * sizeof(T) + 7) / 8) * 8 + rows_pad * 8;   // staged rows + the two (padded) row tables
+        const size_t bytes = size_t(P.lds_rows + 2) * K * 8 + rows_pad * 8;   // staged rows, later fp64 accumulators + the two (padded) row tables
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps);
     };
     bool launched = false;
-    if constexpr (K == 5 && sizeof(T) == 8) {     // ablations and the phase probe (tools/probe_patch.py)
+    if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
         if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
             launched = true;
             if (tb.block == 512) {
@@ -515,7 +519,8 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         else launch(k_patch_apply<T, K, 256, 0>, 256);
     }
     if (part && defer) {
-        hipLaunchKernelGGL(k_patch_dot<K>, dim3(nb), dim3(256), 0, s, tb.npatch, (const double *)P.ppart, part, scal, step);
+        // (a few workgroups: the rows of `part` behind them stay zero - cleared by the solver once per solve)
+        hipLaunchKernelGGL(k_patch_dot<K>, dim3(nb < kPatchDotBlocks ? nb : kPatchDotBlocks), dim3(256), 0, s, tb.npatch, (const double *)P.ppart, part, scal, step);
         return;
     }
     if (part) hipLaunchKernelGGL((k_patch_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, tb.npatch, tb.bptr, tb.bslot, (const T *)P.Yb, y, (const double *)P.ppart, part, scal, step);

@@ -174,6 +174,7 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
     for (int i = 0; i < ctx->progress_len; ++i) ctx->progress[i].step = -1;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     HIP_TRY(hipMemsetAsync(buf.rz0, 0, kScalarSlots * sizeof(double), s));   // forwarded totals + done flag + floor
+    if (buf.defer_q) HIP_TRY(hipMemsetAsync(buf.part_pq, 0, sizeof(double) * kMaxPartialBlocks * 8, s));   // the patch operator's dot launch fills only its first rows
     if (floor) {
         std::memcpy(ctx->floor_stage, floor, sizeof(double) * REMO_MAX_RHS);
         HIP_TRY(hipMemcpyAsync(buf.rz0 + 5 * 8, ctx->floor_stage, sizeof(double) * REMO_MAX_RHS, hipMemcpyHostToDevice, s));
@@ -202,7 +203,7 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
             }
         }
         if (!replaced) launch_pcg_update(A, k, step, tol2, buf, s);
-        launch_pcg_direction(A, k, step, tol2, buf, s);
+        launch_pcg_direction(A, k, step, tol2, buf, s, !replaced);
         ++step;
         if (*done_step >= 0) { done = true; break; }   // the device froze every column: the queued launches are no-ops
         if (step % check == 0) {
@@ -1250,7 +1251,7 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     }
 }
 
-int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, double *out16) {
+int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, double *out16) {
     if (!ctx || !b || !out16) return REMO_ERR_ARG;
     if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");
     const int k = 5;
@@ -1269,13 +1270,40 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, double *out16) {
         HIP_TRY(hipMemset(st, 0, sizeof(long long) * grid * 8));
         const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
         set_patch_stamps(st); set_patch_mode(4);
-        for (int rep = 0; rep < 3; ++rep) launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
+        if (fp32) {     // the fp32 instantiation on the same tables (vectors reinterpreted: timing only)
+            CsrViewT<float> A32{n, 0, nullptr, nullptr, nullptr};
+            PatchOpT<float> P32{b->patch64.t, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, b->patch64.lds_rows};
+            A32.patch = &P32; A32.vertex_block_only = true;
+            for (int rep = 0; rep < 3; ++rep) launch_spmm(A32, k, reinterpret_cast<const float *>(dx), reinterpret_cast<float *>(dy), nullptr, nullptr, nb, ctx->stream);
+        } else {
+            for (int rep = 0; rep < 3; ++rep) launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
+        }
         set_patch_mode(0); set_patch_stamps(nullptr);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // the whole application (apply + reduce launches) under the ablation modes 0 .. 3, microseconds per application
+        for (int mode = 0; mode <= 3; ++mode) {
+            set_patch_mode(mode);
+            CsrViewT<float> A32{n, 0, nullptr, nullptr, nullptr};
+            PatchOpT<float> P32{b->patch64.t, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, b->patch64.lds_rows};
+            A32.patch = &P32; A32.vertex_block_only = true;
+            auto once = [&]() {
+                if (fp32) launch_spmm(A32, k, reinterpret_cast<const float *>(dx), reinterpret_cast<float *>(dy), nullptr, nullptr, nb, ctx->stream);
+                else launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
+            };
+            once();
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            for (int rep = 0; rep < 10; ++rep) once();
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+            out16[10 + mode] = 1e3 * double(ms) / 10.0;
+        }
+        set_patch_mode(0);
         std::vector<long long> h(size_t(grid) * 8);
         HIP_TRY(hipMemcpy(h.data(), st, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
         (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(st);
-        for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+        for (int i = 0; i < 10; ++i) out16[i] = 0.0;
         long long lo = LLONG_MAX, hi = 0;
         int64_t cnt = 0;
         for (int64_t w = 0; w < grid; ++w) {

@@ -263,8 +263,10 @@ class Model:
     def simulate_logs(self, measurement_depths, domain_radius=50, batch_size=5, mesh_generator="auto", preconditioner="multigrid",
                       condense=True, mesh_provider: Optional[Callable] = None, mesh_scale: Optional[float] = None, rtol: float = 1e-8,
                       maxsteps: int = 1000, verbose: bool = True, mesh_workers: Optional[int] = None, precision: str = "fp64",
-                      schedule: str = "static"):
+                      schedule: str = "static", solver_options: Optional[dict] = None):
+        """solver_options: further keywords of solver.make_opts for every batch (op, coarse, quadrature, assemble, ...)."""
         from . import solver, sweep
+        extra = dict(solver_options or {})
         start = time.time()
         measurement_depths = np.asarray(measurement_depths, dtype=float)
         alert = False
@@ -296,7 +298,7 @@ class Model:
         mud = np.interp(simulation_depths, self.borehole_model[:, 0], self.borehole_model[:, 2])
         if verbose and sweep.rank() == 0:
             print("{} simulation tasks prepared".format(len(batches)))
-        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision)
+        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision, **extra)
         tuned_coarse = mesh_provider is None and preconditioner == "multigrid"     # the default 3D provider = conforming revolved meshes
 
         n_tools = len(self.tools)
@@ -400,7 +402,7 @@ class Model:
                     # and a wider interval than the library's default for isotropic meshes of the same vertex count
                     # (GPU scan, tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)
                     rel = max(mesh.n_nodes, 1) / 12600.0
-                    bopts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision,
+                    bopts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision, **extra,
                                              coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))),
                                              coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
                 c = free_ctx.get()

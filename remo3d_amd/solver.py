@@ -149,9 +149,14 @@ class Batch:
         self.n_rhs = len(sources)
         self.stats = None
 
-    def run(self, opts: Optional[RemoOpts] = None, raise_on_error=True):
+    def run(self, opts: Optional[RemoOpts] = None, raise_on_error=True, ctx: Optional["Context"] = None):
+        """ctx: run on ANOTHER context of the same GPU than the one that uploaded the batch (its arrays are plain device memory:
+        an uploader context can bring the next batch in while the solver context works on this one).  The batch stays with
+        that context from then on (system / solution of the run live in its arena)."""
         st = RemoStats()
         o = opts if opts is not None else make_opts()
+        if ctx is not None:
+            self.ctx = ctx
         rc = self._L.remo_batch_run(self.ctx._h, self._h, C.byref(o), C.byref(st))
         self.stats = st.as_dict()
         if rc < 0 and raise_on_error:

@@ -1,19 +1,20 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE / read-request-size passes of the default bench workload (one counter per pass, kernel trace only),
-# condensed on the box by tools/pmc_traffic.py.  usage (GPU box, repo root): bash tools/collect_traffic.sh OUT_JSON
+# HBM traffic of the operator application of the bench workload: FETCH_SIZE / WRITE_SIZE / read-request-size passes (one counter
+# group per pass, kernel trace only - never with the trace domains gpurun refuses), condensed on the box by tools/pmc_traffic.py.
+# The profiled run builds its meshes in-process (no child processes behind the profiler's preloaded library), so it takes the
+# first 20 depths of the headline sweep (8 batches) instead of 100: per-launch averages, same kernels, same mesh sizes.
+# usage (GPU box, repo root): bash tools/collect_traffic.sh OUT_JSON [bench args...]
 set -e
-OUT=$(realpath -m $1)
+OUT=$(realpath -m $1); shift
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-( while true; do sleep 45; echo "heartbeat $(date +%T)"; done ) &
-HB=$!
-trap "kill $HB" EXIT
-rm -rf /tmp/pf /tmp/pw
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --mesh-workers 1 > /tmp/bench_pf.json 2> /tmp/pf.err
+export REMO_BENCH_TRACE_MESH=1
+ARGS="--steps 1 --warmup 0 --depths 20 --no-cpu --no-extras --mesh-workers 1 $@"
+rm -rf /tmp/pf /tmp/pw /tmp/pr
+timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 $REPO/bench.py $ARGS > /tmp/bench_pf.json 2> /tmp/pf.err || { tail -5 /tmp/pf.err; exit 1; }
 echo "fetch pass done"
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --mesh-workers 1 > /tmp/bench_pw.json 2> /tmp/pw.err
+timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 $REPO/bench.py $ARGS > /tmp/bench_pw.json 2> /tmp/pw.err || { tail -5 /tmp/pw.err; exit 1; }
 echo "write pass done"
-rm -rf /tmp/pr
-timeout -k 10 500 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d /tmp/pr -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --mesh-workers 1 > /tmp/bench_pr.json 2> /tmp/pr.err
+timeout -k 10 500 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d /tmp/pr -- python3 $REPO/bench.py $ARGS > /tmp/bench_pr.json 2> /tmp/pr.err || { tail -5 /tmp/pr.err; exit 1; }
 echo "request-size pass done"
 python3 $REPO/tools/pmc_traffic.py /tmp/pf /tmp/pw /tmp/bench_pf.json $OUT /tmp/pr

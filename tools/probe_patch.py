@@ -11,11 +11,17 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     only = None
     coarse = "auto"
+    precision = "fp64"
+    block = 256
     for a in sys.argv[1:]:
         if a.startswith("--ops="):
             only = a[6:].split(",")
         if a.startswith("--coarse="):
             coarse = a[9:]
+        if a.startswith("--precision="):
+            precision = a[12:]
+        if a.startswith("--block="):
+            block = int(a[8:])
     sizes = args or ["S"]
     work = {}
     for sz in sizes:
@@ -25,6 +31,7 @@ def main():
         print("mesh %s: T=%d built in %.1f s" % (sz, work[sz]["mesh"].n_elems, time.time() - t0), flush=True)
     from remo3d_amd import _lib, solver
     L = _lib.load()
+    L.remo_debug_tune(19, block)
     out = []
     with solver.Context(0) as ctx:
         for sz in sizes:
@@ -38,7 +45,7 @@ def main():
                 if mode and not only:
                     continue
                 L.remo_debug_tune(21, 0)
-                rc = b.run(solver.make_opts(rtol=1e-8, op=op, coarse=coarse), raise_on_error=False)
+                rc = b.run(solver.make_opts(rtol=1e-8, op=op, coarse=coarse, precision=precision, assemble=("full" if op != "patch" else "auto")), raise_on_error=False)
                 st = dict(b.stats)
                 n = st["n_free"]
                 x = np.random.default_rng(0).standard_normal((n, 5))
@@ -56,10 +63,12 @@ def main():
                 print(json.dumps(rec), flush=True)
                 if name == "patch":
                     import ctypes as C
-                    ph = (C.c_double * 16)()
-                    if L.remo_debug_patch_phases(ctx._h, b._h, ph) == 0:
-                        names = ["tables", "stage x", "x->regs", "zero", "arith+accumulate", "output", "partials", "workgroup", "launch span", "workgroups"]
-                        print("phases (clock ticks): " + "  ".join("%s %.0f" % (nm, ph[i]) for i, nm in enumerate(names)), flush=True)
+                    for fp32 in (0, 1):
+                        ph = (C.c_double * 16)()
+                        if L.remo_debug_patch_phases(ctx._h, b._h, fp32, ph) == 0:
+                            names = ["tables", "stage x", "x->regs", "zero", "arith+accumulate", "output", "partials", "workgroup", "launch span", "workgroups"]
+                            print("phases %s (clock ticks): " % ("fp32" if fp32 else "fp64") + "  ".join("%s %.0f" % (nm, ph[i]) for i, nm in enumerate(names))
+                                  + "  | application us: full %.1f  no-atomics %.1f  no-arithmetic %.1f  no-output %.1f" % (ph[10], ph[11], ph[12], ph[13]), flush=True)
             b.close()
     return out
 

@@ -140,9 +140,7 @@ int patch_elements_per_group(int kmax);
 
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)
-// with_x: the launch also forms x += alpha p of this step (every step but the residual replacements of the mixed mode, whose
-// update launch has done it: launch_pcg_replace)
-template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s, bool with_x = true);
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s);
 void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s);
 // B = A_vv D^-1 A_vv (and A_vv itself) on the pattern of B, rows sorted; cnt / rowptr [nv + 1], col / a / b [capacity];

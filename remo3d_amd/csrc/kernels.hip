@@ -782,8 +782,8 @@ template void launch_spmm<float>(const CsrViewT<float> &, int, const float *, fl
 // Jacobi-PCG vector kernels (CGSolver(a.mat, c.mat), ngsolve_functions.py:50-51), K columns at
 // once with per-column step lengths.  Three launches per step:
 //   spmm      q = A p, partials of <p,q>
-//   update    alpha = <Cr,r>/<p,q>;  r -= alpha q;  partials of <C r, r>
-//   direction beta = <Cr,r>_new/<Cr,r>_old;  x += alpha p;  p = C r + beta p      (p and x are passed over once)
+//   update    alpha = <Cr,r>/<p,q>;  x += alpha p;  r -= alpha q;  partials of <C r, r>
+//   direction beta = <Cr,r>_new/<Cr,r>_old;  p = C r + beta p
 // Scalars never visit the host: every block re-reduces the (<= 1024 x K) per-block partials of
 // the previous launch in a fixed order, so results are bit-reproducible and there is no atomic.
 // A column whose <Cr,r> has dropped below tol^2 <Cr0,r0> (or that broke down) is frozen
@@ -921,8 +921,9 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             const int32_t rs = fold.rowptr[row], re = fold.rowptr[row + 1];
             const int64_t at = row * K + mycol;
             T di = T(0), rn = T(0);
-            if (mine) {     // (x += alpha p is the direction launch's, which reads p anyway)
+            if (mine) {
                 di = dinv[row];
+                x[at] += a_mine * p[at];
                 rn = r[at] - a_mine * q[at];
             }
             T t[K];
@@ -969,9 +970,11 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             for (int c = 0; c < K; ++c) qi[c] = q[i * K + c];
         }
 #pragma unroll
-        for (int c = 0; c < K; ++c) {     // x += alpha p: in the direction launch, which reads p anyway (one pass over p and x less here)
+        for (int c = 0; c < K; ++c) {
             const T a = T(alpha[c]);
+            const T xi = x[i * K + c] + a * p[i * K + c];
             const T ri = r[i * K + c] - a * qi[c];
+            x[i * K + c] = xi;
             r[i * K + c] = ri;
             acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels
         }
@@ -1074,12 +1077,10 @@ template <class T, int K>
 __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgsT<T> ch,
                                                        const double *__restrict__ part_rz_new, double *__restrict__ scal,
                                                        const T *__restrict__ r, T *__restrict__ p,
-                                                       const T *__restrict__ dinv, T *__restrict__ x /* nullptr: x is not this launch's */) {
+                                                       const T *__restrict__ dinv) {
     __shared__ double smem[16 * K];
     if (solve_done(scal, step)) return;
-    double beta[K], alpha[K];      // alpha: the step length of THIS step (x += alpha p_old rides on the pass over p)
-#pragma unroll
-    for (int c = 0; c < K; ++c) alpha[c] = 0.0;
+    double beta[K];
     if (first) {  // p0 = C r0
 #pragma unroll
         for (int c = 0; c < K; ++c) beta[c] = 0.0;
@@ -1091,7 +1092,6 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
             const double pq = scal[8 + c], rzo = scal[16 + 8 * (step & 1) + c];   // forwarded by the update launch
             const bool live = (rzo > tol2 * scal[c]) && (rzo > scal[kFloorSlot + c]) && (pq > 0.0);
             beta[c] = live ? rzn[c] / rzo : 0.0;
-            alpha[c] = live ? rzo / pq : 0.0;       // exactly the update launch's alpha (same operands, same test)
         }
         if (blockIdx.x == 0 && threadIdx.x == 0)
 #pragma unroll
@@ -1102,13 +1102,13 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
     constexpr int U = 4;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
-        T d[U], zv[U][K], pv[U][K], xv[U][K];
+        T d[U], zv[U][K], pv[U][K];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             d[u] = T(0);
 #pragma unroll
-            for (int c = 0; c < K; ++c) { zv[u][c] = T(0); pv[u][c] = T(0); xv[u][c] = T(0); }
+            for (int c = 0; c < K; ++c) { zv[u][c] = T(0); pv[u][c] = T(0); }
             if (i < n) {
                 d[u] = dinv[i];
                 const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
@@ -1117,24 +1117,17 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
                 if (!first)
 #pragma unroll
                     for (int c = 0; c < K; ++c) pv[u][c] = p[i * K + c];
-                if (!first && x)
-#pragma unroll
-                    for (int c = 0; c < K; ++c) xv[u][c] = x[i * K + c];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
-            if (i < n) {
+            if (i < n)
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     const T zi = d[u] * zv[u][c];
                     p[i * K + c] = first ? zi : zi + T(beta[c]) * pv[u][c];
                 }
-                if (!first && x)
-#pragma unroll
-                    for (int c = 0; c < K; ++c) x[i * K + c] = xv[u][c] + T(alpha[c]) * pv[u][c];
-            }
         }
     }
 }
@@ -1556,7 +1549,7 @@ template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f,
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_init<T, KK>), dim3(g), dim3(256), 0, s, n, ch, f, b.dinv, b.x, b.r, b.p, b.part_rz));
     launch_cheb(A, k, 0, b, b.part_rz, s);
     if (ch.nv > 0)
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv, (T *)nullptr));
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 1, 0, 0.0, nb_rz(b), ch, b.part_rz, b.rz0, b.r, b.p, b.dinv));
 }
 
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {
@@ -1626,12 +1619,12 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     launch_cheb(A, k, step, b, nxt, s);
 }
 
-template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s, bool with_x) {
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<T> ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv, with_x ? b.x : (T *)nullptr));
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv));
 }
 
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s) {
@@ -1642,7 +1635,7 @@ template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &
 #define REMO_INSTANTIATE_PCG(T)                                                                                          \
     template void launch_pcg_init<T>(const CsrViewT<T> &, int, const T *, const PcgBuffersT<T> &, hipStream_t);          \
     template void launch_pcg_update<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);      \
-    template void launch_pcg_direction<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t, bool);   \
+    template void launch_pcg_direction<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);   \
     template void launch_pcg_final<T>(int, int, const PcgBuffersT<T> &, hipStream_t);
 REMO_INSTANTIATE_PCG(double)
 REMO_INSTANTIATE_PCG(float)

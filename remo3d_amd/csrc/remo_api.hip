@@ -203,7 +203,7 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
             }
         }
         if (!replaced) launch_pcg_update(A, k, step, tol2, buf, s);
-        launch_pcg_direction(A, k, step, tol2, buf, s, !replaced);
+        launch_pcg_direction(A, k, step, tol2, buf, s);
         ++step;
         if (*done_step >= 0) { done = true; break; }   // the device froze every column: the queued launches are no-ops
         if (step % check == 0) {
@@ -526,9 +526,10 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        // element result slab(s) of the element-wise operator: when it is asked for, or may be chosen by size (the stored-entry
-        // count is only known after the numbering: nnz_max / 8 is a safe lower bound of what a 3D mesh produces)
-        if (dim == 3 && (o.op == 1 || (o.op == 0 && nnz_max / 8 > 17000000)))
+        // element result slab(s) of the round-2 element-wise operator: only when it is asked for, or (patch operator switched off
+        // by the probe knob) may be chosen by size - a run that ends on the patch operator or the CSR product never pays for it
+        const bool reserve_elem = dim == 3 && (o.op == 1 || (o.op == 0 && !g_auto_patch && nnz_max / 8 > 17000000));
+        if (reserve_elem)
             need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;
         const bool want_patch = dim == 3 && (o.op == 3 || o.op == 0);
         if (want_patch) need += patch_arena_bytes(nt, ndof_max, kmax) + size_t(nt) * 20 * size_t(kmax) * 8;   // tables + boundary slab (upper bound)
@@ -741,7 +742,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
         const bool patch_op = patch_ok && (lite || o.op == 3 || (o.op == 0 && g_auto_patch));
-        const bool elem_op = !patch_op && dim == 3 && elem_fits && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));
+        const bool elem_op = !patch_op && dim == 3 && elem_fits && reserve_elem && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));   // (else: the CSR product)
         st->op_used = patch_op ? 3 : (elem_op ? 1 : 0);
         if (patch_op) {
             ptab.nslot_cap = h_patch[2] > 0 ? h_patch[2] : 1;     // the slab holds the slots in use

@@ -268,7 +268,7 @@ def pmc_traffic(workload, n_free, nnz, op="csr"):
         return None
     size = re.search(r"mesh size (\w+)", workload or "")
     if size and p.get("mesh_size") == size.group(1) and p.get("operator", "csr") == op:
-        return p["spmm"]["traffic_bytes_per_launch"]
+        return dict(bytes=p["spmm"]["traffic_bytes_per_launch"], n_free=p.get("n_free"), mesh_T=p.get("mesh_T"))
     return None
 
 
@@ -412,8 +412,12 @@ def roofline_of(agg, precision, stride, workload_name=None):
     y written once, 40 bytes of local indices + 48 of metric terms per element - no stored entries)."""
     ach = (agg["spmv_bytes_total"] / 1e9) / (agg["spmv_ms"] / 1e3) if agg["spmv_ms"] > 0 else None
     op = {0: "csr", 1: "element", 3: "patch"}.get(int(agg.get("op_used", 0)), "csr")
+    tr = pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"]), op) if (workload_name and precision == "fp64") else None
     r = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
-             traffic=pmc_traffic(workload_name, int(agg["n"]), int(agg["nnz"]), op) if (workload_name and precision == "fp64") else None)
+             traffic=tr["bytes"] if tr else None)
+    if tr:     # the counter passes ran on the first batches of the 20-depth sweep of the same mesh size (in-process meshing under the profiler)
+        r["traffic_measured_on"] = dict(n_free=tr["n_free"], mesh_T=tr["mesh_T"],
+                                        algorithmic_bytes_there=(16.0 * 5 * tr["n_free"] + 88.0 * tr["mesh_T"]) if op == "patch" and tr["n_free"] and tr["mesh_T"] else None)
     prec = "fp64" if precision == "fp64" else "fp32 values and vectors"
     kernel = {"csr": "k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)",
               "element": "k_elem_apply + k_elem_reduce (element-wise operator with a slab of element results, %s; `achieved` prices the CSR product's bytes)",

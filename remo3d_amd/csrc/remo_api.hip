@@ -738,7 +738,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
         // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
-        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24);
+        const size_t patch_lds = size_t(h_patch[1] + 2) * size_t(kmax) * 8 + size_t(h_patch[1] + 12 * (256 / kmax)) * 8;   // what k_patch_apply asks for (kernels.hip patch_applies)
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= 60 * 1024;
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
         const bool patch_op = patch_ok && (lite || o.op == 3 || (o.op == 0 && g_auto_patch));

@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kPatchDotBlocks = 32;                    // workgroups of k_patch_dot
 constexpr int kPatchPasses = 12;                       // k_patch_apply: loads a lane keeps in flight
-constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 8192 (E <= 256: patch_elements_per_group)
+constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 4096 < 8192 (E <= 204: patch_elements_per_group)
 constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
 
 // ---- tables ------------------------------------------------------------------------------------------------------------
@@ -429,8 +429,8 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
 int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
 void set_patch_block(int b) { g_patch_block = (b == 512) ? 512 : 256; }
-// one lane per (element, right-hand side); at most 256 elements (the table builder sorts 20 slots per element in LDS)
-int patch_elements_per_group(int kmax) { const int e = g_patch_block / (kmax > 0 ? kmax : 1); return e < 256 ? e : 256; }
+// one lane per (element, right-hand side); at most 204 elements (the table builder sorts 20 slots per element in 32 KB of LDS)
+int patch_elements_per_group(int kmax) { const int e = g_patch_block / (kmax > 0 ? kmax : 1); return e < 204 ? e : 204; }   // 204 x 20 slots sort in 4096 LDS keys
 
 size_t patch_arena_bytes(int64_t nt, int64_t n_max, int kmax) {
     const int E = patch_elements_per_group(kmax);

@@ -74,14 +74,16 @@ typedef struct {
                                several contexts driven by several host threads only ONE batch is in its PCG at any time while the
                                others number / assemble theirs beside it (software pipelining across batches); 0: no lock      */
     int32_t op;             /* how the CG applies A (CGSolver's a.mat, ngsolve_functions.py:50-51):
-                               2 = CSR SpMM on the assembled matrix;
-                               1 = element-wise (3D only; 2D always uses the CSR product): every tetrahedron applies its own K_e
-                                   through the factorised reference tensors and the rows sum their elements' results - same
-                                   operator to rounding, no stored entries read;
-                               0 = by size (default): element-wise in 3D once the matrix no longer stays in the 256 MB of
-                                   Infinity Cache between launches (more than 17 M stored entries: there the element-wise form takes
-                                   24-26 % less time than the CSR product, below it the CSR product is 20 % ahead), else CSR.
-                               The matrix is assembled either way (Jacobi diagonal, P1 block of the preconditioner, inspection hooks) */
+                               3 = patch operator (3D only; 2D always uses the CSR product): matrix-free - the element list is cut
+                                   into patches of 256 / k tetrahedra, a workgroup stages the x rows of its patch in LDS, applies every
+                                   K_e through the factorised reference tensors and writes each row once (rows shared by patches through
+                                   a compact slab); same operator to rounding; results reproducible to rounding, not bit for bit (LDS
+                                   atomics) - the one kernel of the path for which that holds;
+                               2 = CSR SpMM on the assembled matrix (bit-reproducible);
+                               1 = element-wise with a slab of element results (round 2; kept for comparison);
+                               0 = default: 3 in 3D (at the reference's resolution an application takes 125 us against 372-450 us
+                                   of the CSR product and moves 0.4 GB instead of 1.25 GB), 2 in 2D.
+                               What is assembled: remo_opts_t.assemble */
     int32_t coarse;         /* "multigrid": the solver of the P1 (vertex) block.
                                1 = Chebyshev polynomial (coarse_degree, coarse_ratio);
                                2 = one V(1,1) cycle of a smoothed-aggregation multigrid hierarchy built per batch on the device

@@ -13,6 +13,7 @@ def main():
     coarse = "auto"
     precision = "fp64"
     block = 256
+    tunes = []
     for a in sys.argv[1:]:
         if a.startswith("--ops="):
             only = a[6:].split(",")
@@ -22,6 +23,8 @@ def main():
             precision = a[12:]
         if a.startswith("--block="):
             block = int(a[8:])
+        if a.startswith("--tune="):
+            tunes.append(tuple(int(v) for v in a[7:].split("=")))
     sizes = args or ["S"]
     work = {}
     for sz in sizes:
@@ -32,6 +35,8 @@ def main():
     from remo3d_amd import _lib, solver
     L = _lib.load()
     L.remo_debug_tune(19, block)
+    for key, val in tunes:
+        L.remo_debug_tune(key, val)
     out = []
     with solver.Context(0) as ctx:
         for sz in sizes:

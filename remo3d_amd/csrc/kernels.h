@@ -95,6 +95,15 @@ template <class T> struct PatchOpT {
     double *ppart = nullptr;           // [npatch][8] <x, y> of every patch's own rows
     int lds_rows = 0;                  // largest pcount: sizes the kernel's LDS
 };
+constexpr int kPatchPasses = 12;   // staging passes a lane's registers hold (k_patch_apply)
+// dynamic LDS of k_patch_apply: staged k-wide rows (later the fp64 accumulators; + the zero row and one of slack) and the two
+// row tables padded to whole staging passes; a workgroup may ask for 64 KB less the kernel's static 128 k bytes
+inline size_t patch_lds_bytes(int lds_rows, int k, int block) {
+    const int pass = kPatchPasses * (block / k);
+    return size_t(lds_rows + 2) * size_t(k) * 8 + size_t((lds_rows + pass - 1) / pass) * pass * 8;
+}
+constexpr size_t kPatchLdsLimit = 63 * 1024;
+
 
 template <class T> struct CsrViewT {
     int64_t n;
@@ -135,6 +144,7 @@ template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *
 template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
 void set_patch_block(int threads);   // 256 (default) or 512
+void set_patch_slab_rows(int v);     // 1: boundary slab row-major (0: patch-major)
 void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps
 int patch_elements_per_group(int kmax);
 

@@ -739,7 +739,7 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 }
 
 template <class T> bool patch_applies(const CsrViewT<T> &A, int k) {
-    return A.patch && k * A.patch->t.E <= A.patch->t.block && size_t(A.patch->lds_rows + 2) * k * 8 + size_t(A.patch->lds_rows + 12 * (A.patch->t.block / k)) * 8 <= 60 * 1024;
+    return A.patch && k * A.patch->t.E <= A.patch->t.block && patch_lds_bytes(A.patch->lds_rows, k, A.patch->t.block) <= kPatchLdsLimit;
 }
 template bool patch_applies<double>(const CsrViewT<double> &, int);
 template bool patch_applies<float>(const CsrViewT<float> &, int);

@@ -34,7 +34,6 @@ namespace remo {
 namespace {
 
 constexpr int kPatchDotBlocks = 32;                    // workgroups of k_patch_dot
-constexpr int kPatchPasses = 12;                       // k_patch_apply: loads a lane keeps in flight
 constexpr uint32_t kSlotBits = 13;                      // element dof slots of a patch: E * 20 <= 4096 < 8192 (E <= 204: patch_elements_per_group)
 constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts behind every row
 
@@ -150,7 +149,8 @@ __global__ void __launch_bounds__(256) k_patch_zero_rows(int64_t nslots, uint16_
 // patches of the row] = that slot.
 __global__ void __launch_bounds__(256) k_patch_slots(int E, int rows_cap, const int32_t *__restrict__ pcount, const int32_t *__restrict__ pboff,
                                                      const int32_t *__restrict__ prow, int32_t *__restrict__ pout, const int32_t *__restrict__ adjptr,
-                                                     const uint32_t *__restrict__ adj, const int32_t *__restrict__ bptr, int32_t *__restrict__ bslot) {
+                                                     const uint32_t *__restrict__ adj, const int32_t *__restrict__ bptr, int32_t *__restrict__ bslot,
+                                                     int row_major) {
     __shared__ int32_t cnts[256];
     const int tid = threadIdx.x;
     const int64_t p = blockIdx.x;
@@ -173,8 +173,10 @@ __global__ void __launch_bounds__(256) k_patch_slots(int E, int rows_cap, const 
             rank += q != last;
             last = q;
         }
-        pout[p * rows_cap + m] = slot;
-        bslot[bptr[row] + rank] = slot;
+        // row_major: the slots of a row lie side by side instead (the readers stream, the patch's stores scatter)
+        const int32_t at = row_major ? bptr[row] + rank : slot;
+        pout[p * rows_cap + m] = at;
+        bslot[bptr[row] + rank] = at;
         ++slot;
     }
 }
@@ -427,6 +429,8 @@ long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of pha
 void set_patch_mode(int mode) { g_patch_mode = mode; }
 void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
+int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
+void set_patch_slab_rows(int v) { g_patch_slab_rows = v ? 1 : 0; }
 int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
 void set_patch_block(int b) { g_patch_block = (b == 512) ? 512 : 256; }
 // one lane per (element, right-hand side); at most 204 elements (the table builder sorts 20 slots per element in 32 KB of LDS)
@@ -478,7 +482,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     (void)rocprim::exclusive_scan(tmp, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
     hipLaunchKernelGGL(k_patch_zero_rows, dim3(1024), dim3(256), 0, s, nt * 20, lidx, (const int32_t *)(flag_and_max + 1));
     hipLaunchKernelGGL(k_patch_slots, dim3(int(out.npatch)), dim3(256), 0, s, E, rows_cap, (const int32_t *)pcount, (const int32_t *)pboff, (const int32_t *)prow, pout,
-                       sy.adjptr, sy.adj, (const int32_t *)bptr, bslot);
+                       sy.adjptr, sy.adj, (const int32_t *)bptr, bslot, g_patch_slab_rows);
     (void)hipMemcpyAsync(flag_and_max + 2, bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use
     ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
     out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.bptr = bptr; out.bslot = bslot;
@@ -492,9 +496,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     const dim3 grid(int(per * 8));
     double *pp2 = pp;
     auto launch = [&](auto kernel, int blk) {
-        const int pass = kPatchPasses * (blk / K);
-        const size_t rows_pad = size_t((P.lds_rows + pass - 1) / pass) * pass;
-        const size_t bytes = size_t(P.lds_rows + 2) * K * 8 + rows_pad * 8;   // staged rows, later fp64 accumulators + the two (padded) row tables
+        const size_t bytes = patch_lds_bytes(P.lds_rows, K, blk);   // staged rows, later fp64 accumulators + the two (padded) row tables
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps);
     };
     bool launched = false;

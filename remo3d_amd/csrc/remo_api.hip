@@ -583,7 +583,12 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // The paired (root-product) form must stay in fp64: in fp32 storage it needs MORE steps at degree 16 and breaks down above.
         const double nv2 = double(sy.nvfree > 0 ? sy.nvfree : 1) / 25000.0;
         const int deg2 = 2 * int(std::min(16.0, std::max(8.0, std::floor(8.0 * std::sqrt(nv2) + 0.5))));
-        const int deg_default = (dim == 3) ? int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.9)))) : deg2;
+        // round 3, size L with the patch operator (83 k vertices, tools/scan_coarse3d_fine.py L, profiles/r03_scan_coarse_L.log): steps per
+        // four batches 675 / 637 / 638 / 630 / 601 at degrees 11 / 12 / 13 / 14 / 16 - an odd degree above 7 buys nothing over the even one
+        // below it (M: 8 best, 7 and 9 worse) - solve 300 / 289 / 295 / 297 / 294 ms: even degrees from 8 up
+        int deg3 = int(std::min(16.0, std::max(5.0, std::floor(5.0 * std::sqrt(nv_rel) + 0.9))));
+        if (deg3 > 8) deg3 &= ~1;
+        const int deg_default = (dim == 3) ? deg3 : deg2;
         const double ratio_default = (dim == 3) ? std::min(1200.0, std::max(60.0, 90.0 * std::pow(nv_rel, 2.0 / 3.0))) : std::min(2400.0, std::max(600.0, 600.0 * nv2 * 1.25));
         buf.cheb_degree = two_level ? (o.coarse_degree > 0 ? o.coarse_degree : deg_default) : 0;
         buf.cheb_lmax = buf.cheb_lmin = 0.0;
@@ -738,8 +743,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
         // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
-        const size_t patch_lds = size_t(h_patch[1] + 2) * size_t(kmax) * 8 + size_t(h_patch[1] + 12 * (256 / kmax)) * 8;   // what k_patch_apply asks for (kernels.hip patch_applies)
-        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= 60 * 1024;
+        const size_t patch_lds = ptab.block > 0 ? patch_lds_bytes(h_patch[1], kmax, ptab.block) : 0;   // what k_patch_apply asks for (kernels.hip patch_applies)
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= kPatchLdsLimit;
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
         const bool patch_op = patch_ok && (lite || o.op == 3 || (o.op == 0 && g_auto_patch));
@@ -1338,6 +1343,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 20) g_auto_patch = value;
     else if (key == 21) set_patch_mode(value);
     else if (key == 22) g_defer_q = value;
+    else if (key == 23) set_patch_slab_rows(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

@@ -45,6 +45,11 @@ template <class T> struct PcgBuffersT {
     // preconditioner may be inexact); nullptr -> the chain runs in T.  Float copies of the compact block's values and of the
     // vertex rows' Jacobi factors, chain vectors [nv_coarse * k]
     const float *c32_val = nullptr, *c32_dinv = nullptr;
+    // fixed-width image of the vertex block for the Chebyshev launches (launch_vblock_ell): [nv][kEllWidth] columns and values,
+    // [nv][2] begin / end of a row's further entries in the arrays the chain reads otherwise; nullptr -> rows are walked as CSR
+    const int32_t *ell_col = nullptr, *ell_tail = nullptr;
+    const T *ell_val = nullptr;
+    const float *c32_ell_val = nullptr;
     float *c32_z = nullptr, *c32_res = nullptr, *c32_d[2] = {nullptr, nullptr};
     // multigrid cycle on the vertex block instead of the polynomial (amg.h; 2D by default); nullptr -> Chebyshev
     const AmgT<T> *amg = nullptr;
@@ -160,6 +165,12 @@ constexpr int kSquareSlots = 512;
 void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int32_t *sq_rowptr, int32_t *sq_col, double *sq_a, double *sq_b,
                           int64_t capacity, int32_t *flag, hipStream_t s);
 int cheb_grid(int64_t nv);
+
+constexpr int kEllWidth = 24;   // entries per row of the fixed-width image: three per lane at eight lanes per row (3D P1 rows hold ~15)
+// eval64 / eval32: either may be nullptr
+void launch_vblock_ell(int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int32_t *ecol, int32_t *tail, double *eval64,
+                       float *eval32, hipStream_t s);
+
 
 // mixed precision: conversions around the fp32 inner solve
 void launch_to_float(int64_t n, const double *src, float *dst, hipStream_t s);

@@ -993,12 +993,15 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 // TC = storage type of the chain (block values, Jacobi factors, directions, residual, running z): T, or float inside an fp64
 // solve (large vertex blocks: the launches are HBM streams there, and a preconditioner may be applied inexactly - the
 // recurrences of x and r never see it).  r (read) and the finished z (written for the direction kernel) stay in T.
-template <class T, class TC, int K, bool FIRST, int LAST>
+// ELL: the first kEllWidth entries of a row come from the fixed-width image (ecol, eval; k_vblock_ell) and `rowptr` holds the
+// begin / end PAIRS of the entries beyond them in (col, val).
+template <class T, class TC, int K, bool FIRST, int LAST, bool ELL = false>
 __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const TC *__restrict__ val, const TC *__restrict__ dinv,
                                                    const TC *__restrict__ d_old, TC *__restrict__ d_new,
                                                    TC *__restrict__ zc, TC *__restrict__ res, T *__restrict__ z, double c1_, double c2_, double inv_theta_,
-                                                   T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit, int step) {
+                                                   T *__restrict__ r, double *__restrict__ part, const double *__restrict__ scal, int commit, int step,
+                                                   const int32_t *__restrict__ ecol = nullptr, const TC *__restrict__ eval = nullptr) {
     const TC c1 = TC(c1_), c2 = TC(c2_), inv_theta = TC(inv_theta_);
     constexpr int LPR = 8, RPB = 256 / LPR;
     constexpr bool SAME = sizeof(T) == sizeof(TC);
@@ -1014,7 +1017,18 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
     const bool mine = own[0] != 0;
     double dot = 0.0;
     for (int64_t row = int64_t(blockIdx.x) * RPB + grp; row < nv; row += int64_t(gridDim.x) * RPB) {
-        const int32_t rs = rowptr[row], re = rowptr[row + 1];
+        constexpr int NE = ELL ? kEllWidth / LPR : 1;
+        int32_t ej[NE];
+        TC ev[NE];
+        int32_t rs, re;
+        if constexpr (ELL) {
+            const int64_t eb = row * kEllWidth + sub;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) { ej[u] = ecol[eb + u * LPR]; ev[u] = eval[eb + u * LPR]; }
+            rs = rowptr[2 * row]; re = rowptr[2 * row + 1];
+        } else {
+            rs = rowptr[row]; re = rowptr[row + 1];
+        }
         const int64_t at = row * K + mycol;
         TC di = TC(0), dold_in = TC(0), z_in = TC(0), res_in = TC(0);
         T rr = T(0);
@@ -1031,6 +1045,22 @@ __global__ void __launch_bounds__(256) k_cheb_step(int64_t nv, const int32_t *__
         TC t[K];
 #pragma unroll
         for (int c = 0; c < K; ++c) t[c] = TC(0);
+        if constexpr (ELL) {
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int32_t j = ej[u];
+                const TC v = FIRST ? ev[u] * dinv[j] * inv_theta : ev[u];
+                if (FIRST) {
+                    const T *dj = r + int64_t(j) * K;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) t[c] += v * TC(dj[c]);
+                } else {
+                    const TC *dj = d_old + int64_t(j) * K;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) t[c] += v * dj[c];
+                }
+            }
+        }
         for (int32_t p = rs + sub; p < re; p += LPR) {
             const int32_t j = col[p];
             if (j >= nv) break;  // columns ascend: the vertex block leads the row
@@ -1319,6 +1349,42 @@ void launch_vblock_compact(int64_t nv, const CsrView &A, int32_t *vb_rowptr, int
                        capacity, flag);
 }
 
+// Fixed-width image of the vertex block for the Chebyshev launches.  A launch on the CSR form is a chain of dependent round
+// trips per row - row bounds, then columns and values (once per eight entries), then the gathered vector rows - on a block that
+// lives in the caches: latency, not bytes.  Here the first kEllWidth entries of row i sit at [i][0 .. kEllWidth) (padded with
+// (i, 0)), so a lane asks for all its columns and values at once, then for all the vector rows: two trips.  tail[i] = the
+// begin / end of the row's remaining entries in the arrays the image was made from (equal: none - the usual case).
+__global__ void __launch_bounds__(256) k_vblock_ell(int64_t nv, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, int32_t *__restrict__ ecol, int32_t *__restrict__ tail,
+                                                    double *__restrict__ eval64, float *__restrict__ eval32) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= nv * kEllWidth) return;
+    const int64_t row = i / kEllWidth;
+    const int e = int(i - row * kEllWidth);
+    const int32_t rs = rowptr[row], re = rowptr[row + 1];
+    int32_t c = int32_t(row);
+    double v = 0.0;
+    if (rs + e < re) {
+        const int32_t j = col[rs + e];
+        if (j < nv) { c = j; v = val[rs + e]; }     // columns ascend: the vertex block leads a row of the whole matrix
+    }
+    ecol[i] = c;
+    if (eval64) eval64[i] = v;
+    if (eval32) eval32[i] = float(v);
+    if (e == 0) {
+        const int32_t end = lower_bound_col(col, rs, re, int32_t(nv));
+        const bool more = end - rs > kEllWidth;
+        tail[2 * row] = more ? rs + kEllWidth : 0;
+        tail[2 * row + 1] = more ? end : 0;
+    }
+}
+
+void launch_vblock_ell(int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int32_t *ecol, int32_t *tail, double *eval64,
+                       float *eval32, hipStream_t s) {
+    if (nv <= 0) return;
+    hipLaunchKernelGGL(k_vblock_ell, dim3(int((nv * kEllWidth + 255) / 256)), dim3(256), 0, s, nv, rowptr, col, val, ecol, tail, eval64, eval32);
+}
+
 void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int32_t *sq_rowptr, int32_t *sq_col, double *sq_a, double *sq_b,
                           int64_t capacity, int32_t *flag, hipStream_t s) {
     if (nv <= 0) return;
@@ -1510,6 +1576,8 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
     const T *vval = b.vb_rowptr ? b.vb_val : A.val;
     // fp32 chain inside an fp64 solve: needs the compact block (its float copy), never together with the folded first step
     const bool chain32 = sizeof(T) == 8 && b.c32_val != nullptr && b.vb_rowptr != nullptr && !first_done;
+    // the fixed-width image of the block (k_vblock_ell) in the storage type of the chain, if the host made one
+    const bool ell = b.ell_col != nullptr && b.ell_tail != nullptr && (chain32 ? b.c32_ell_val != nullptr : b.ell_val != nullptr);
     for (int j = 0; j < launches; ++j) {
         const double rho_new = 1.0 / (2.0 * sig - rho);
         const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
@@ -1524,19 +1592,24 @@ template <class T> static void launch_cheb(const CsrViewT<T> &A, int k, int step
         // 17.9 us per launch under rocprofv3, profiles/r01_f_kernel_stats_sizeL_10depths_before_grid_fix.csv; after: 14.2 us, …_after_grid_fix.csv)
         const int64_t g_rows = (b.nv_coarse + 31) / 32;
         const int gl = last ? g : int(g_rows < 8192 ? g_rows : 8192);
-#define REMO_CHEB(F, L)                                                                                                                             \
+#define REMO_CHEB_E(F, L, E)                                                                                                                        \
     if (chain32) {                                                                                                                                  \
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, float, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, b.c32_val, b.c32_dinv, \
-                                            (const float *)b.c32_d[j & 1], b.c32_d[(j + 1) & 1], b.c32_z, b.c32_res, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, 0, step)); \
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, float, KK, F, L, E>), dim3(gl), dim3(256), 0, s, b.nv_coarse, E ? b.ell_tail : vrow, vcol, b.c32_val, b.c32_dinv, \
+                                            (const float *)b.c32_d[j & 1], b.c32_d[(j + 1) & 1], b.c32_z, b.c32_res, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, 0, step, \
+                                            b.ell_col, b.c32_ell_val));                                                                             \
     } else {                                                                                                                                        \
-        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, T, KK, F, L>), dim3(gl), dim3(256), 0, s, b.nv_coarse, vrow, vcol, vval, b.dinv, dold, dnew, \
-                                            b.cz, b.cres, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, commit, step));                                     \
+        REMO_K_SWITCH(k, hipLaunchKernelGGL((k_cheb_step<T, T, KK, F, L, E>), dim3(gl), dim3(256), 0, s, b.nv_coarse, E ? b.ell_tail : vrow, vcol, vval, b.dinv, dold, dnew, \
+                                            b.cz, b.cres, b.cz, c1, c2, inv_theta, b.r, part, b.rz0, commit, step, b.ell_col, b.ell_val));               \
     }
+#define REMO_CHEB(F, L)                \
+    if (ell) { REMO_CHEB_E(F, L, true) } \
+    else { REMO_CHEB_E(F, L, false) }
         if (first && last) { if (b.cheb_degree == 1) { REMO_CHEB(true, 1); } else { REMO_CHEB(true, 2); } }
         else if (first) { REMO_CHEB(true, 0); }
         else if (last) { REMO_CHEB(false, 2); }
         else { REMO_CHEB(false, 0); }
 #undef REMO_CHEB
+#undef REMO_CHEB_E
     }
 }
 

@@ -147,6 +147,7 @@ int g_amg32 = 1;     // key 17: 1 = fp64 solves run the multigrid cycle in fp32 
 int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 inline bool g_auto_patch_ok(int op);
+int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
 int g_auto_patch = 1; // key 20: 1 = op 0 takes the patch operator in 3D whenever its tables fit (default), 0 = the round-2 choice by size
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
@@ -536,6 +537,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
+        need += size_t(nv + 64) * kEllWidth * 12 + size_t(nv + 64) * 8;        // its fixed-width image
         need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
         const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2 && o.coarse_degree <= 0));   // an explicit degree asks for the polynomial
         if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * 2 + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
@@ -707,6 +709,19 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             buf.c32_z = ctx->take<float>(nc); buf.c32_res = ctx->take<float>(nc);
             buf.c32_d[0] = ctx->take<float>(nc); buf.c32_d[1] = ctx->take<float>(nc);
         }
+        // fixed-width image of the vertex block for the polynomial's launches (kernels.hip k_vblock_ell; remo_debug_tune key 24: 0 = off)
+        int32_t *ell_col = nullptr, *ell_tail = nullptr;
+        if (g_ell && two_level && !want_amg && !want_square && dim == 3) {
+            const int64_t nvc = buf.nv_coarse;
+            const bool from_block = buf.vb_rowptr != nullptr;
+            ell_col = ctx->take<int32_t>(size_t(nvc) * kEllWidth + 8);
+            ell_tail = ctx->take<int32_t>(size_t(nvc) * 2 + 8);
+            double *e64 = (o.precision == 0 && !buf.c32_val) ? ctx->take<double>(size_t(nvc) * kEllWidth + 8) : nullptr;
+            float *e32 = (o.precision != 0 || buf.c32_val) ? ctx->take<float>(size_t(nvc) * kEllWidth + 8) : nullptr;
+            launch_vblock_ell(nvc, from_block ? buf.vb_rowptr : sy.rowptr, from_block ? buf.vb_col : sy.col, from_block ? buf.vb_val : d_val,
+                              ell_col, ell_tail, e64, e32, s);
+            buf.ell_col = ell_col; buf.ell_tail = ell_tail; buf.ell_val = e64; buf.c32_ell_val = e32;
+        }
         if (two_level && want_amg) {   // multigrid cycle on the vertex block instead of the polynomial (amg.hip)
             std::string why;
             if (amg_setup(ctx->ar, s, dim, buf.nv_coarse, sy.rowptr, sy.col, d_val, kmax, b->amg64, why)) buf.amg = &b->amg64;
@@ -811,6 +826,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
                 launch_to_float(h_vb[1], buf.vb_val, vb32, s);
                 f.vb_rowptr = buf.vb_rowptr; f.vb_col = buf.vb_col; f.vb_val = vb32;
             }
+            f.ell_col = buf.ell_col; f.ell_tail = buf.ell_tail; f.ell_val = buf.c32_ell_val;
             if (buf.sq_rowptr) {
                 float *a32 = ctx->take<float>(size_t(h_sq[1]) + 1), *b32 = ctx->take<float>(size_t(h_sq[1]) + 1);
                 launch_to_float(h_sq[1], buf.sq_a, a32, s);
@@ -1344,6 +1360,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 21) set_patch_mode(value);
     else if (key == 22) g_defer_q = value;
     else if (key == 23) set_patch_slab_rows(value);
+    else if (key == 24) g_ell = value;
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

@@ -34,6 +34,11 @@ int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
  * launch; [9] workgroups.  The last run on the batch must have used the patch operator. */
 int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *batch, int32_t fp32 /* the fp32 instantiation instead */, double *out16);
 
+/* Cost of a grid-wide barrier between the resident workgroups of one launch (nblocks <= 2048 workgroups of 256 threads; nbar
+ * iterations of: agent-scope store, barrier, agent-scope load of another workgroup's store, barrier): out3[0] = microseconds per
+ * barrier, [1] = 1 if a wait gave up, [2] = loads that did not see the store. */
+int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, double *out3);
+
 /* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
  * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
  * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;

@@ -166,6 +166,8 @@ void launch_vblock_square(int64_t nv, const CsrView &A, const double *dinv, int3
                           int64_t capacity, int32_t *flag, hipStream_t s);
 int cheb_grid(int64_t nv);
 
+// probe of a grid-wide barrier (remo_debug_grid_barrier): nblocks must not exceed what the chip holds at once; counter / fail / mismatch zeroed by the caller
+void launch_barrier_probe(int nblocks, int nbar, unsigned *counter, int *fail, float *buf, int *mismatch, hipStream_t s);
 constexpr int kEllWidth = 24;   // entries per row of the fixed-width image: three per lane at eight lanes per row (3D P1 rows hold ~15)
 // eval64 / eval32: either may be nullptr
 void launch_vblock_ell(int64_t nv, const int32_t *rowptr, const int32_t *col, const double *val, int32_t *ecol, int32_t *tail, double *eval64,

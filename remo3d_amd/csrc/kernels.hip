@@ -1349,6 +1349,52 @@ void launch_vblock_compact(int64_t nv, const CsrView &A, int32_t *vb_rowptr, int
                        capacity, flag);
 }
 
+// ---- grid barrier (probe and, if it pays, the Chebyshev chain as one launch) ---------------------------------------------------
+// Every workgroup of a launch whose workgroups are all resident (grid <= what the chip holds at once: the caller's duty) arrives
+// at a counter that only grows - arrival e of nblocks workgroups waits for e * nblocks - and leaves when all have.  Data that
+// crosses the barrier is written and read with agent-scope accesses (the eight L2s of the chip are not coherent with each other
+// for plain ones).  A wait gives up after kBarrierSpins polls and raises *fail: every wave reaches the end of the kernel.
+constexpr long long kBarrierSpins = 1ll << 22;
+__device__ __forceinline__ bool grid_barrier(unsigned *counter, unsigned nblocks, unsigned &epoch, int *fail) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++epoch;
+        const unsigned target = epoch * nblocks;
+        __atomic_thread_fence(__ATOMIC_RELEASE);   // (agent scope is HIP's default for the builtin)
+        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > kBarrierSpins || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { good = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!good) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+__global__ void __launch_bounds__(256) k_barrier_probe(unsigned nblocks, int nbar, unsigned *counter, int *fail, float *buf, int *mismatch) {
+    unsigned epoch = 0;
+    const unsigned other = (blockIdx.x + 37u) % nblocks;
+    int bad = 0;
+    for (int it = 0; it < nbar; ++it) {
+        __hip_atomic_store(buf + size_t(blockIdx.x) * 256 + threadIdx.x, float(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!grid_barrier(counter, nblocks, epoch, fail)) return;
+        const float v = __hip_atomic_load(buf + size_t(other) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad += (v != float(it + 1)) ? 1 : 0;
+        if (!grid_barrier(counter, nblocks, epoch, fail)) return;     // nobody overwrites what a neighbour still reads
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
+void launch_barrier_probe(int nblocks, int nbar, unsigned *counter, int *fail, float *buf, int *mismatch, hipStream_t s) {
+    hipLaunchKernelGGL(k_barrier_probe, dim3(nblocks), dim3(256), 0, s, unsigned(nblocks), nbar, counter, fail, buf, mismatch);
+}
+
 // Fixed-width image of the vertex block for the Chebyshev launches.  A launch on the CSR form is a chain of dependent round
 // trips per row - row bounds, then columns and values (once per eight entries), then the gathered vector rows - on a block that
 // lives in the caches: latency, not bytes.  Here the first kEllWidth entries of row i sit at [i][0 .. kEllWidth) (padded with

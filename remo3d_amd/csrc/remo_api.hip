@@ -1274,6 +1274,40 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *b, int32_t k, const double *x
     }
 }
 
+int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, double *out3) {
+    if (!ctx || !out3 || nblocks < 1 || nblocks > 2048 || nbar < 1 || nbar > 100000) return REMO_ERR_ARG;
+    unsigned *counter = nullptr;
+    float *buf = nullptr;
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&counter), 64));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(float) * size_t(nblocks) * 256));
+        int *fail_flag = reinterpret_cast<int *>(counter) + 4, *mismatch = reinterpret_cast<int *>(counter) + 8;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {     // the second run is the measurement
+            HIP_TRY(hipMemsetAsync(counter, 0, 64, ctx->stream));
+            HIP_TRY(hipMemsetAsync(buf, 0, sizeof(float) * size_t(nblocks) * 256, ctx->stream));
+            HIP_TRY(hipEventRecord(e0, ctx->stream));
+            launch_barrier_probe(nblocks, nbar, counter, fail_flag, buf, mismatch, ctx->stream);
+            HIP_TRY(hipEventRecord(e1, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        }
+        int h[12];
+        HIP_TRY(hipMemcpy(h, counter, sizeof h, hipMemcpyDeviceToHost));
+        out3[0] = 1e3 * double(ms) / (2.0 * nbar);    // two barriers per iteration
+        out3[1] = h[4]; out3[2] = h[8];
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(counter); (void)hipFree(buf);
+        return REMO_OK;
+    } catch (const std::exception &e) {
+        (void)hipFree(counter); (void)hipFree(buf);
+        return fail(ctx, REMO_ERR_DEVICE, e.what());
+    }
+}
+
 int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, double *out16) {
     if (!ctx || !b || !out16) return REMO_ERR_ARG;
     if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");

@@ -633,7 +633,7 @@ def main():
                            batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
                            points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg["n"]), nnz=int(agg["nnz"]), rtol=args.rtol,
                            maxsteps=args.maxsteps, precision=args.precision, streams_per_gpu=args.streams, operator={0: "csr", 1: "element", 3: "patch"}.get(int(agg["op_used"]), "csr"),
-                           preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 13 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
+                           preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 12 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
                            max_pcg_iterations=int(agg["max_it"]), batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum())),
                roofline=roofline_of(agg, args.precision, stride, workload_name),
                breakdown_ms_per_step=dict(numbering_and_pattern_device=agg["ms_symbolic"], h2d_points=agg["ms_h2d"], assemble=agg["ms_assemble"], solve=agg["ms_solve"],

@@ -345,6 +345,9 @@ class Runner:
         agg["spmv_ms"] += st["spmv_ms"]; agg["spmv_launches"] += st["spmv_launches"]
         agg["spmv_ms_raw"] += st["spmv_ms_raw"]; agg["ev_over"] = st["event_overhead_ms"]
         agg["spmv_bytes_total"] += st["spmv_bytes"] * st["spmv_launches"]
+        krhs = max(1, len(w["sources"]))
+        agg["spmv_flops_total"] = agg.get("spmv_flops_total", 0.0) + st["spmv_launches"] * float(
+            PATCH_FLOPS_PER_ELEMENT_COLUMN * w["mesh"].n_elems * krhs if st["op_used"] == 3 else 2.0 * st["nnz"] * krhs)
         agg["pcg_steps"] += st["pcg_steps"]; agg["max_it"] = max(agg["max_it"], st["max_iterations"])
         for k in ("ms_symbolic", "ms_assemble", "ms_solve", "ms_h2d", "ms_eval"):
             agg[k] += st[k]
@@ -406,6 +409,13 @@ def timed(runner, steps, warmup, sync, **kw):
     return time.time() - t0, slab, agg, busy
 
 
+# fp64 work of the patch operator per (element, right-hand side): 427 v_fmac_f64 + 90 v_add_f64 + 83 v_mul_f64 in the ISA of
+# k_patch_apply<double, 5, 256> (tools/kernel_resources.py leaves it in /tmp; counters: profiles/r03_pmc_sq_counters_patch_L_final.txt)
+PATCH_FLOPS_PER_ELEMENT_COLUMN = 2 * 427 + 90 + 83
+# MI355X fp64 vector rate = its fp64 matrix rate: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 x 2.4 GHz (half the guide's fp32 figure)
+FP64_PEAK_TFLOPS = 78.6
+
+
 def roofline_of(agg, precision, stride, workload_name=None):
     """The operator application of the CG (what `time_kernels` brackets: every launch of it) against the HBM roofline, priced by
     ITS OWN algorithmic bytes (remo_stats_t.spmv_bytes): CSR product 12 nnz + 4 n + 16 k n; patch operator 16 k n + 88 T (x read and
@@ -435,6 +445,14 @@ def roofline_of(agg, precision, stride, workload_name=None):
              bytes_per_launch=formula,
              algorithmic_bytes_per_launch=(agg["spmv_bytes_total"] / agg["spmv_launches"]) if agg["spmv_launches"] else None,
              traffic_unit="bytes per application: reads sized by the TCC_EA0_RDREQ 32/64/128-B request counters + WRITE_SIZE over the kernels of the bracket, " + PMC_FILE)
+    # the compute side of the same launches: a matrix-free operator trades bytes for arithmetic, and above ~10 flop per byte
+    # (78.6 TFLOP/s over 8 TB/s) the fp64 rate is the roof that binds, not HBM
+    fl = agg.get("spmv_flops_total", 0.0)
+    if fl > 0 and agg["spmv_ms"] > 0 and precision == "fp64":
+        tf = fl / (agg["spmv_ms"] / 1e3) / 1e12
+        r["compute"] = dict(flops_per_launch=fl / agg["spmv_launches"], achieved_tflops=tf, peak_tflops=FP64_PEAK_TFLOPS, frac=tf / FP64_PEAK_TFLOPS,
+                            flop_per_algorithmic_byte=fl / agg["spmv_bytes_total"], machine_balance_flop_per_byte=FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
+                            note="fp64 vector (= matrix) rate of MI355X; flops counted from the kernel's ISA (patch operator) or 2 nnz k (CSR product)")
     return r
 
 

@@ -302,7 +302,12 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
 #pragma unroll
             for (int i = 0; i < 20; ++i) yv[i] = xv[i] * c11;
         } else {
-            REMO_ELEM_GRAD(T, xv, g, ElemTables<T>::grad())
+            // fp64: ONE base address of each factor table in scalar registers (left to itself the compiler forms the address anew,
+            // three scalar instructions, before each of its 48 s_load_dwordx16)
+            typedef const T __attribute__((address_space(4))) *ctab_t;
+            ctab_t tgrad = (ctab_t)ElemTables<T>::grad(), tdiv = (ctab_t)ElemTables<T>::div();
+            if constexpr (sizeof(T) == 8) { asm volatile("" : "+s"(tgrad)); asm volatile("" : "+s"(tdiv)); }
+            REMO_ELEM_GRAD(T, xv, g, tgrad)
             T dd = T(0);
 #pragma unroll
             for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
                 g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
             }
             d0 = double(dd);
-            REMO_ELEM_DIV(T, g, yv, ElemTables<T>::div())
+            REMO_ELEM_DIV(T, g, yv, tdiv)
         }
         // the local rows are read a second time for the accumulation (an L1 / L2 hit) instead of being held in ten registers
         // through the tensor arithmetic: that is the difference between three and four waves per SIMD in fp64

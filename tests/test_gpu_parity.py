@@ -446,6 +446,75 @@ def test_compact_vertex_block_is_the_same_operator(precision, mesh3d, gpu_ctx):
         b.close()
 
 
+def _hub_mesh():
+    """A ball of tetrahedra around a HUB vertex with ~45 neighbours (a shell of points with nothing else inside it): vertex rows of
+    the P1 block far longer than the 24 entries of the fixed-width image, next to ordinary ones."""
+    from scipy.spatial import Delaunay
+    from remo3d_amd.meshgen import Mesh, _boundary_facets
+    rng = np.random.default_rng(11)
+
+    def sphere(m, radius):
+        v = rng.standard_normal((m, 3))
+        return radius * v / np.linalg.norm(v, axis=1)[:, None]
+    hub = np.array([[0.0, 0.0, 0.05]])
+    pts = np.concatenate([hub, hub + sphere(44, 1.0), sphere(160, 2.2) * rng.uniform(0.85, 1.0, (160, 1)),
+                          sphere(300, 4.0) * rng.uniform(0.7, 1.0, (300, 1)), sphere(260, 6.0)])
+    conn = Delaunay(pts).simplices.astype(np.int32)
+    p = pts[conn]
+    vol = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
+    conn = conn[np.abs(vol) > 1e-9]
+    flip = vol[np.abs(vol) > 1e-9] < 0
+    conn[flip] = conn[flip][:, [1, 0, 2, 3]]
+    mat = (np.linalg.norm(pts[conn].mean(axis=1), axis=1) > 2.0).astype(np.int32)
+    bconn = _boundary_facets(conn).astype(np.int32)
+    return Mesh(3, np.ascontiguousarray(pts), np.ascontiguousarray(conn), mat, bconn, np.ones(len(bconn), np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_fixed_width_vertex_block_with_long_rows(precision, gpu_ctx):
+    """The Chebyshev launches read the first 24 entries of a vertex row from a fixed-width image and the rest from the CSR form
+    (remo_debug_tune key 24; kernels.hip k_vblock_ell): on a mesh whose hub vertex has ~45 neighbours the image, the CSR form and
+    the oracle give the same potentials, with the block read in place or from its compact copy (key 13) and the first step
+    inside the update launch or on its own (key 9)."""
+    from remo3d_amd import _lib, solver
+    from oracle.fem_oracle import Oracle
+    L = _lib.load()
+    mesh = _hub_mesh()
+    import itertools
+    pairs = np.unique(np.sort(np.concatenate([mesh.conn[:, [i, j]] for i, j in itertools.combinations(range(4), 2)]), axis=1), axis=0)
+    deg = np.bincount(pairs.ravel(), minlength=mesh.n_nodes) + 1
+    assert deg[0] > 40 and (deg > 24).sum() >= 3 and np.median(deg) < 24, (deg[0], (deg > 24).sum())
+    sigma = [0.5, 0.05]
+    src, ev = [([0.4], [1.0]), ([-0.6, 0.9], [1.0, -1.0])], [[1.2, -1.5, 0.05], [0.0, 2.5]]
+    o = Oracle(mesh, sigma, condense=True)
+    ref = []
+    for (z, I), ez in zip(src, ev):
+        f, se, sf = o.rhs(z, I)
+        u, it, rr, rc = o.pcg(f, 1e-12, 50000)
+        assert rc == 0
+        ref.append(o.eval(u, ez, (se, sf)))
+    b = gpu_ctx.batch(mesh, sigma, src, ev)
+    try:
+        got = {}
+        for ell in (0, 1):
+            for compact in (0, 2):
+                for fold in (1, 0):
+                    L.remo_debug_tune(24, ell); L.remo_debug_tune(13, compact); L.remo_debug_tune(9, fold)
+                    assert b.run(solver.make_opts(rtol=1e-11, precision=precision, coarse_degree=6, coarse_ratio=30, op="csr")) == 0
+                    assert b.stats["coarse_used"] == 1
+                    got[(ell, compact, fold)] = (np.concatenate(b.fetch()), b.stats["pcg_steps"])
+        base = got[(0, 0, 1)]
+        for key, (u, steps) in got.items():
+            assert np.allclose(u, base[0], rtol=1e-8, atol=0), key
+            # (fp32 inner solves: the image sums a row in another order than the CSR walk, and the refinement cycles amplify that)
+            assert abs(steps - base[1]) <= max(2, base[1] // (50 if precision == "fp64" else 15)), (key, steps, base[1])
+        assert np.allclose(base[0], np.concatenate(ref), rtol=(1e-7 if precision == "fp64" else 1e-6), atol=0)
+    finally:
+        L.remo_debug_tune(24, 1); L.remo_debug_tune(13, 1); L.remo_debug_tune(9, 1)
+        b.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 5, 8])
 def test_element_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):

@@ -516,6 +516,28 @@ def test_fixed_width_vertex_block_with_long_rows(precision, gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nrhs", [1, 2, 8])
+def test_patch_operator_on_a_hub_mesh(nrhs, gpu_ctx):
+    """A vertex shared by ~80 tetrahedra: its row is spread over several patches (boundary slab slots summed by the update
+    launch), with 256 / nrhs elements per patch; same potentials as the CSR product, with and without the assembled matrix."""
+    from remo3d_amd import solver
+    mesh = _hub_mesh()
+    sigma = [0.5, 0.05]
+    zs = np.linspace(-1.4, 1.6, nrhs)
+    src = [([float(z)], [1.0]) for z in zs]
+    ev = [[float(z) + 0.7, 0.05] for z in zs]
+    b = gpu_ctx.batch(mesh, sigma, src, ev)
+    try:
+        assert b.run(solver.make_opts(rtol=1e-11, op="csr")) == 0 and b.stats["op_used"] == 0
+        ref = np.concatenate(b.fetch())
+        for assemble in ("full", "vertex_block"):
+            assert b.run(solver.make_opts(rtol=1e-11, op="patch", assemble=assemble)) == 0 and b.stats["op_used"] == 3
+            assert np.allclose(np.concatenate(b.fetch()), ref, rtol=1e-8, atol=0), assemble
+    finally:
+        b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 5, 8])
 def test_element_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
     """remo_opts_t.op = 1 (3D): y = A x element by element through the factorised reference tensors equals the CSR product and

@@ -194,8 +194,11 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
 // <x, A x> is summed element by element as g . h (g = B x, h = c~ g: x^T B^T c~ B x): complete when this launch ends, no second
 // look at x.  MODE != 0: ablations for tools/probe_patch.py (wrong results on purpose): 1 = plain stores instead of the LDS
 // atomics, 2 = no tensor arithmetic (y = x), 3 = nothing leaves the workgroup.
-template <class T, int K, int BLK, int MODE = 0>
-__global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+// LEAN: the register-lean order of phase 2 (five waves per SIMD instead of four in fp64): the gradient chain runs input by input
+// straight from the staged rows in LDS (no x[20] in registers), BEFORE the staging area is recycled; the metric terms are asked for
+// after it; the divergence chain hands every group of outputs to the LDS accumulators as soon as it is complete (no y[20]).
+template <class T, int K, int BLK, int MODE = 0, bool LEAN = false>
+__global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
                                                      double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps) {
     if (scal && solve_done(scal, step)) return;
     // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
@@ -232,9 +235,11 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
         const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);   // 40-byte records: 8-byte aligned
 #pragma unroll
         for (int q = 0; q < 10; ++q) li[q] = pl[q];
-        const double *ce = tb.C + e * 6;                               // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+        if constexpr (!(LEAN && MODE != 2)) {
+            const double *ce = tb.C + e * 6;                           // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+            for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+        }
     }
     // 1a. the patch's row tables into LDS (one round trip; the output phase finds them there again).  prow holds -1 behind a
     // patch's last row, so no row count has to arrive first; the LDS copies are padded with -1 to whole passes of 1b.
@@ -278,23 +283,73 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
     __syncthreads();
     REMO_STAMP(2)
     // 2. my element, my column
+    double d0 = 0.0;
+    double *ya = lds_raw;
+#define REMO_PATCH_L(i) ((li[(i) >> 1] >> (16 * ((i) & 1))) & 0xFFFFu)      /* local row of dof i; constrained dofs: the zero row (k_patch_zero_rows) */
+    if constexpr (LEAN && MODE != 2) {
+        typedef const T __attribute__((address_space(4))) *ctab_t;
+        ctab_t tgi = (ctab_t)ElemTables2<T>::grad_in(), tdo = (ctab_t)ElemTables2<T>::div_out();
+        if constexpr (sizeof(T) == 8) { asm volatile("" : "+s"(tgi)); asm volatile("" : "+s"(tdo)); }
+        T g[30];
+#define REMO_PATCH_XL(i) xs[REMO_PATCH_L(i) * K + c0]
+        // (lanes without an element read row 0 and drop the result.)  Scheduling barriers between the blocks of the chain: fp32
+        // (factors are literals) 72 registers with them, 88 without; fp64 (factors arrive by scalar loads) must not wait per block
+#define REMO_BAR_ON __builtin_amdgcn_sched_barrier(0);
+#define REMO_BAR_OFF
+        if constexpr (sizeof(T) == 4) { REMO_ELEM_GRAD_IN(T, REMO_PATCH_XL, g, tgi, REMO_BAR_ON) }
+        else { REMO_ELEM_GRAD_IN(T, REMO_PATCH_XL, g, tgi, REMO_BAR_OFF) }
+#undef REMO_PATCH_XL
+        // (pin the chain HERE: its results are used only behind the barriers, inside a branch, and the compiler would sink the
+        // arithmetic there - keeping all twenty x values and every factor alive across the barriers)
+#pragma unroll
+        for (int j = 0; j < 30; ++j) asm volatile("" : "+v"(g[j]));
+        __builtin_amdgcn_sched_barrier(0);                   // the metric terms are NOT wanted in registers during the chain above
+        if (active) {
+            const double *ce = tb.C + e * 6;                 // in flight while the workgroup meets at the two barriers below
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+        }
+        __syncthreads();    // every lane has read its x values: the staging area becomes the accumulators
+        REMO_STAMP(3)
+        for (int j = tid; j < (rows + 1) * K; j += BLK) ya[j] = 0.0;
+        __syncthreads();
+        REMO_STAMP(4)
+        if (active) {
+            const T c11 = T(cm[0]), c12 = T(cm[1]), c13 = T(cm[2]), c22 = T(cm[3]), c23 = T(cm[4]), c33 = T(cm[5]);
+            T dd = T(0);
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
+                const T g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
+                const T h1 = c11 * g1 + c12 * g2 + c13 * g3, h2 = c12 * g1 + c22 * g2 + c23 * g3, h3 = c13 * g1 + c23 * g2 + c33 * g3;
+                dd += g1 * h1 + g2 * h2 + g3 * h3;
+                g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
+            }
+            d0 = double(dd);
+            if constexpr (sizeof(T) == 8) {      // fp64: the local rows are fetched again (an L1 / L2 hit) rather than held through h = c~ g
+                const uint32_t *pl2 = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);
+#pragma unroll
+                for (int q = 0; q < 10; ++q) li[q] = __builtin_nontemporal_load(pl2 + q);
+            }
+#define REMO_PATCH_EMIT(i, v) { if constexpr (MODE == 1) ya[REMO_PATCH_L(i) * K + c0] = double(v); else lds_add(ya + REMO_PATCH_L(i) * K + c0, double(v)); }
+            if constexpr (sizeof(T) == 4) { REMO_ELEM_DIV_OUT(T, g, tdo, REMO_PATCH_EMIT, REMO_BAR_ON) }
+            else { REMO_ELEM_DIV_OUT(T, g, tdo, REMO_PATCH_EMIT, REMO_BAR_OFF) }
+#undef REMO_PATCH_EMIT
+#undef REMO_BAR_ON
+#undef REMO_BAR_OFF
+        }
+    } else {
     T xv[20];
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;      // constrained dofs: the zero row (k_patch_zero_rows)
-            xv[i] = xs[l * K + c0];
-        }
+        for (int i = 0; i < 20; ++i) xv[i] = xs[REMO_PATCH_L(i) * K + c0];
     }
     __syncthreads();        // every lane holds its x values: the staging area becomes the accumulators
     REMO_STAMP(3)
     // the accumulators are fp64 whatever T is: ds_add_f32 runs at about a lane per clock on this chip (measured: 204 of the 304 us
     // of the fp32 kernel at 443 k tetrahedra were its 20 atomics per lane; ds_add_f64 costs 4 us there)
-    double *ya = lds_raw;
     for (int j = tid; j < (rows + 1) * K; j += BLK) ya[j] = 0.0;
     __syncthreads();
     REMO_STAMP(4)
-    double d0 = 0.0;
     if (active) {
         const T c11 = T(cm[0]), c12 = T(cm[1]), c13 = T(cm[2]), c22 = T(cm[3]), c23 = T(cm[4]), c33 = T(cm[5]);
         T g[30], yv[20];
@@ -328,11 +383,13 @@ __global__ void __launch_bounds__(BLK) k_patch_apply(PatchTables tb, int rows, c
         }
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-            const uint32_t l = (li[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            const uint32_t l = REMO_PATCH_L(i);
             if constexpr (MODE == 1) ya[l * K + c0] = double(yv[i]);
             else lds_add(ya + l * K + c0, double(yv[i]));
         }
     }
+    }
+#undef REMO_PATCH_L
     __syncthreads();
     REMO_STAMP(5)
     // 3. rows of this patch alone -> y; shared rows -> the patch's block of the boundary slab; one value per lane and pass again
@@ -434,6 +491,11 @@ long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of pha
 void set_patch_mode(int mode) { g_patch_mode = mode; }
 void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
+// remo_debug_tune key 26: the register-lean order of the kernel's arithmetic phase (k_patch_apply LEAN): -1 = in fp32 storage only
+// (default: 72 registers and seven waves per SIMD against 104 and four, application 111 against 124 us at 443 k tetrahedra; in
+// fp64 96 registers with spills and five waves against 124 and four: 160 against 156 us), 0 = never, 1 = always
+int g_patch_lean = -1;
+void set_patch_lean(int v) { g_patch_lean = v; }
 int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
 void set_patch_slab_rows(int v) { g_patch_slab_rows = v ? 1 : 0; }
 int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
@@ -523,6 +585,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     }
     if (!launched) {
         if (tb.block == 512) launch(k_patch_apply<T, K, 512, 0>, 512);
+        else if (g_patch_lean == 1 || (g_patch_lean < 0 && sizeof(T) == 4)) launch(k_patch_apply<T, K, 256, 0, true>, 256);
         else launch(k_patch_apply<T, K, 256, 0>, 256);
     }
     if (part && defer) {

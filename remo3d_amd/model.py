@@ -470,9 +470,19 @@ class Model:
         if verbose and sweep.rank() == 0:
             print("\nProcessed in: ", datetime.timedelta(seconds=self.timing["total_s"]))
 
-    # -- results (remo3d.py:902-991; plotting is presentation and out of scope) ---------------------
-    def save_results(self, output_folder=None, measurements_to_save="auto", **plot_options):
+    # -- results (remo3d.py:902-1147): Results_<n>.txt per group of logs on one depth grid + Results_plot.png ------------------
+    def save_results(self, output_folder=None, measurements_to_save="auto", plot_layout="auto", plot_depth_lim="auto", plot_aspect_ratio="auto",
+                     model_rad_lim="auto", model_res_lim="auto", logs_res_lim="auto", logs_at_nan="break", logs_interpolation_factor=1,
+                     logs_colours="auto", plot=True):
+        """Same keywords as the reference (remo3d.py:902-903).  plot=False (this build's addition) skips the picture; without an
+        output folder the reference only shows the figure (a notebook feature): here the figure is returned."""
+        plot_kw = dict(plot_layout=plot_layout, plot_depth_lim=plot_depth_lim, plot_aspect_ratio=plot_aspect_ratio, model_rad_lim=model_rad_lim,
+                       model_res_lim=model_res_lim, logs_res_lim=logs_res_lim, logs_at_nan=logs_at_nan,
+                       logs_interpolation_factor=logs_interpolation_factor, logs_colours=logs_colours)
         if output_folder is None:
+            if plot and self.logs and self.formation_model is not None:
+                from . import plotting
+                return plotting.plot_results(self, None, **plot_kw)
             return None
         sub = os.path.join(output_folder, "Results_{}/".format(datetime.datetime.now().strftime("%Y_%m_%d__%H_%M_%S")))
         os.makedirs(sub, exist_ok=True)
@@ -490,4 +500,10 @@ class Model:
             np.savetxt(path, table, fmt="%.4f", delimiter="\t", header=header, comments="")
             written.append(path)
             n += 1
+        if plot and self.logs and self.formation_model is not None:     # (no picture of a model that was never set)
+            from . import plotting
+            import matplotlib.pyplot as plt
+            fig = plotting.plot_results(self, sub + "Results_plot.png", **plot_kw)
+            plt.close(fig)
+            written.append(sub + "Results_plot.png")
         return written

@@ -128,6 +128,41 @@ def test_results_writer_layout(tmp_path):
     assert lines[3] == "1.1000\t5.1235\t8.0000" and lines[4].endswith("nan")
 
 
+def test_results_picture(tmp_path, examples_dir):
+    """save_results draws what the reference draws (remo3d.py:993-1147): the formation panel (a polygon per layer, one more per
+    invaded zone, the borehole; coloured by resistivity) and the log tracks, as Results_plot.png beside the tables - here for
+    Example_01 with the reference's own committed log as the curves.  The model and the logs are left as they were."""
+    from remo3d_amd import plotting
+    ex = os.path.join(examples_dir, "Example_01")
+    tools = ["B5.7A0.4M", "B4.48A1.62M", "M1.0A0.1B", "A2.0M0.5N", "N0.5M2.0A", "M4.0A0.5B"]
+    gold = np.loadtxt(os.path.join(ex, "Output/Results_2024_08_17__18_59_29/Results_1.txt"), skiprows=2)
+    m = Model(tools)
+    m.set_model_parameters(os.path.join(ex, "Input/Formation.txt"), os.path.join(ex, "Input/Borehole.txt"))
+    m.logs = {t: np.column_stack([gold[:, 0], gold[:, 1 + i]]) for i, t in enumerate(tools)}
+    m.logs[tools[1]][10:13, 1] = np.nan                      # a failed batch
+    before_f, before_l = m.formation_model.copy(), {k: v.copy() for k, v in m.logs.items()}
+    polys, res = plotting.model_polygons(m.formation_model, m.borehole_model, m.dip_deg, [0.0, 25.0], [-1.0, 1.0])
+    invaded = int(np.sum(~np.isnan(m.formation_model[:, 2])))
+    assert len(polys) == len(res) == m.formation_model.shape[0] + invaded + 1
+    assert res[1] == 18.0 and res[2] == 3.0                  # second layer: virgin zone across the picture, flushed zone on top of it
+    assert abs(res[-1] - np.mean(m.borehole_model[:, 2])) < 1e-12 and polys[-1].shape == (2 * m.borehole_model.shape[0], 2)
+    files = m.save_results(str(tmp_path))
+    png = [f for f in files if f.endswith("Results_plot.png")]
+    assert len(png) == 1 and os.path.getsize(png[0]) > 20000 and open(png[0], "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    files = m.save_results(str(tmp_path / "two_tracks"), plot_layout=[tools[:3], tools[3:]], logs_at_nan="continue", logs_interpolation_factor=2,
+                           plot_depth_lim=[5.0, 20.0], model_res_lim=[1.0, 20.0], logs_res_lim=[0.0, 30.0], logs_colours=[["r", "g", "b"], ["k", "c", "m"]])
+    assert os.path.getsize([f for f in files if f.endswith(".png")][0]) > 20000
+    fig = m.save_results(None, plot_layout=[tools[:2], tools[2:4], tools[4:]])
+    assert len(fig.axes) >= 1 + 3 + 1                         # model panel, three tracks (+ their twinned axes), colour bar
+    import matplotlib.pyplot as plt
+    plt.close(fig)
+    with pytest.raises(ValueError):
+        m.save_results(str(tmp_path / "bad"), logs_at_nan="skip")
+    assert np.array_equal(m.formation_model, before_f, equal_nan=True)
+    assert all(np.array_equal(m.logs[k], before_l[k], equal_nan=True) for k in before_l)
+    assert m.save_results(str(tmp_path / "tables_only"), plot=False)[-1].endswith(".txt")
+
+
 @pytest.mark.parametrize("fixture", ["netgen_windows_example_01.json", "netgen_windows_example_01_r5.json", "netgen_windows_bm2.json",
                                      "netgen_windows_bm2_r8.json", "netgen_windows_thin_bedded.json"])
 def test_netgen_path_windowing_matches_reference(fixture, examples_dir):

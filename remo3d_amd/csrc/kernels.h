@@ -149,6 +149,7 @@ template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *
 template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
 void set_patch_block(int threads);   // 256 (default) or 512
+void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
 void set_patch_lean(int v);          // register-lean arithmetic phase of the patch kernel: -1 fp32 only (default), 0 never, 1 always
 void set_patch_slab_rows(int v);     // 1: boundary slab row-major (0: patch-major)
 void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps

@@ -808,6 +808,7 @@ template <class T> struct ChebArgsT {
 template <class T> struct QViewT {
     const int32_t *bptr = nullptr, *bslot = nullptr;
     const T *Yb = nullptr;
+    int ahead = 1;      // 0: the slots of a shared row one by one (remo_debug_tune key 27)
 };
 template <class T> struct FoldArgsT {
     int nb_flat = 0;             // workgroups [0, nb_flat) do the flat update of the rows >= nv, the rest the vertex rows
@@ -958,12 +959,35 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         int32_t b0 = 0, b1 = 0;
         if (qv.bptr) { b0 = qv.bptr[i]; b1 = qv.bptr[i + 1]; }
         if (b1 > b0) {      // a row shared by several patches: its q is still spread over the slab, one slot per patch, ascending
+            // the first kSlabAhead slots without a branch and with all their loads in flight together (slot numbers, then slab
+            // rows: two round trips; the plain loop made two per slot, and a wave waits for its row with the most slots) - a
+            // missing slot reads slot 0 and counts for nothing; further slots (rare) one by one
+            constexpr int kSlabAhead = 4;
+            if (qv.ahead) {
+            int32_t at[kSlabAhead];
 #pragma unroll
-            for (int c = 0; c < K; ++c) qi[c] = T(0);
-            for (int32_t sl = b0; sl < b1; ++sl) {
-                const int64_t at = qv.bslot[sl];
+            for (int j = 0; j < kSlabAhead; ++j) at[j] = qv.bslot[b0 + j < b1 ? b0 + j : b0];
+            T part[kSlabAhead][K];
 #pragma unroll
-                for (int c = 0; c < K; ++c) qi[c] += qv.Yb[at * K + c];
+            for (int j = 0; j < kSlabAhead; ++j)
+#pragma unroll
+                for (int c = 0; c < K; ++c) part[j][c] = qv.Yb[int64_t(at[j]) * K + c];
+#pragma unroll
+            for (int c = 0; c < K; ++c) qi[c] = part[0][c];
+#pragma unroll
+            for (int j = 1; j < kSlabAhead; ++j) {
+                const T w = b0 + j < b1 ? T(1) : T(0);
+#pragma unroll
+                for (int c = 0; c < K; ++c) qi[c] += w * part[j][c];
+            }
+            } else {
+#pragma unroll
+                for (int c = 0; c < K; ++c) qi[c] = T(0);
+            }
+            for (int32_t sl = b0 + (qv.ahead ? kSlabAhead : 0); sl < b1; ++sl) {
+                const int64_t a2 = qv.bslot[sl];
+#pragma unroll
+                for (int c = 0; c < K; ++c) qi[c] += qv.Yb[a2 * K + c];
             }
         } else {
 #pragma unroll
@@ -1521,6 +1545,8 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
     }
 }
 
+int g_slab_ahead = 1;      // remo_debug_tune key 27: 0 = the update launch walks the slab slots of a shared row one by one
+void set_slab_ahead(int v) { g_slab_ahead = v ? 1 : 0; }
 int vec_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > kMaxPartialBlocks / 2) g = kMaxPartialBlocks / 2;
@@ -1690,7 +1716,7 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
         grid = g + int((b.nv_coarse + 31) / 32);   // the vertex workgroups leave no partial sums: one row group each
     }
     QViewT<T> qv;
-    if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; }
+    if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; qv.ahead = g_slab_ahead; }
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
                                         b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, qv));
     launch_cheb(A, k, step, b, nxt, s, folded);

@@ -1396,6 +1396,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 23) set_patch_slab_rows(value);
     else if (key == 24) g_ell = value;
     else if (key == 26) set_patch_lean(value);
+    else if (key == 27) set_slab_ahead(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

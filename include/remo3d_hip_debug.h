@@ -45,7 +45,14 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
  * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
  * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage).  Process-global. */
+ * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage);
+ * round 3: 18: 0 = elements taken in the caller's order (default 1: sorted by their two smallest vertices); 19: threads per workgroup of
+ * the patch kernel, 256 (default) or 512; 20: 0 = op 0 chooses the operator by stored entries as in round 2 (default 1: the patch
+ * operator wherever its tables fit); 21: ablation mode of the patch kernel (1 no LDS atomics, 2 no arithmetic, 3 no output: wrong
+ * results on purpose); 22: 0 = shared rows summed by k_patch_reduce instead of the update launch; 23: 1 = boundary slab row-major
+ * (measured slower); 24: 0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image; 26: register-lean order
+ * of the patch kernel's arithmetic phase: -1 in fp32 storage only (default), 0 never, 1 always; 27: 0 = slab slots of a shared row
+ * fetched one by one in the update launch (default 1: four in flight).  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

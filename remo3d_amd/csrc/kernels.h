@@ -58,11 +58,15 @@ template <class T> struct PcgBuffersT {
     // q once anyway, forms them from the boundary slab itself (one launch and one pass over the slab less per step).  Set by the
     // host when the operator is the patch operator and the update launch does not gather q (no folded Chebyshev step).
     bool defer_q = false;
+    // patch operator, with defer_q: the patches add their <p, A p> into kPqBins rows of part_pq themselves (atomic adds; two sets of
+    // rows taken in turn by step parity, the update launch of a step clears the set of the next) - no launch that folds them
+    bool pq_bins = false;
     PcgProgress *progress;  // mapped host records [progress_len]: one per step, the last one is the "all columns frozen" record
     int progress_len;
     int nb_spmv, nb_vec;    // grid sizes actually used (partials valid for these many blocks)
 };
 using PcgBuffers = PcgBuffersT<double>;
+constexpr int kPqBins = 256;       // rows of a set of <p, A p> bins (PcgBuffersT::pq_bins); set s starts at part_pq + s * kPqBins * 8
 constexpr int kScalarSlots = 48;   // doubles behind PcgBuffersT::rz0
 constexpr int kDoneSlot = 4 * 8;   // rz0[kDoneSlot] (as int): step + 1 of the update launch that froze every column (kernels.hip solve_done)
 
@@ -99,6 +103,7 @@ template <class T> struct PatchOpT {
     T *Yb = nullptr;                   // [nslot_cap][k] boundary slab
     double *ppart = nullptr;           // [npatch][8] <x, y> of every patch's own rows
     int lds_rows = 0;                  // largest pcount: sizes the kernel's LDS
+    bool dot_bins = false;             // PcgBuffersT::pq_bins of the solve that applies it
 };
 constexpr int kPatchPasses = 12;   // staging passes a lane's registers hold (k_patch_apply)
 // dynamic LDS of k_patch_apply: staged k-wide rows (later the fp64 accumulators; + the zero row and one of slack) and the two

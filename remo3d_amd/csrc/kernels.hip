@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                                                     double *__restrict__ part_rz_next, double *__restrict__ rz0,
                                                     PcgProgress *progress, int progress_len, const T *__restrict__ p,
                                                     const T *__restrict__ q, T *__restrict__ x, T *__restrict__ r,
-                                                    const T *__restrict__ dinv, FoldArgsT<T> fold, QViewT<T> qv) {
+                                                    const T *__restrict__ dinv, FoldArgsT<T> fold, QViewT<T> qv, double *__restrict__ clear_bins = nullptr) {
     // scal = rz0[8] | pq[8] | rz of even steps[8] | rz of odd steps[8]: totals forwarded between launches
     // by workgroup 0, so every launch re-reduces only the ONE partial array that is new to it
     __shared__ double smem[16 * 3 * K];
@@ -891,6 +891,9 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             for (int c = 0; c < K; ++c) { rz0[c] = rz[c]; scal[16 + c] = rz[c]; }
         // progress record in mapped host memory: data first, then the step number (system scope)
         publish_progress(progress + (step % (progress_len - 1)), rz, K, step);   // the last slot is the "done" record
+    }
+    if (clear_bins) {     // the patch operator's <p, A p> bins of the NEXT step (PcgBuffersT::pq_bins): this launch is the last reader of that set
+        for (int i = int(blockIdx.x) * int(blockDim.x) + int(threadIdx.x); i < kPqBins * K; i += int(gridDim.x) * int(blockDim.x)) clear_bins[i] = 0.0;
     }
     if (x_only) {   // residual replacement step (mixed precision): r and the <Cr,r> partials come from k_mixed_replace
         for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
@@ -1717,8 +1720,11 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     }
     QViewT<T> qv;
     if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; qv.ahead = g_slab_ahead; }
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, qv));
+    const bool bins = b.pq_bins && b.defer_q && A.patch && !folded;
+    const double *pq_rows = bins ? b.part_pq + (step & 1) * (kPqBins * 8) : b.part_pq;
+    double *pq_clear = bins ? b.part_pq + ((step + 1) & 1) * (kPqBins * 8) : nullptr;
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<T, KK>), dim3(grid), dim3(256), 0, s, n, step, tol2, 0, bins ? kPqBins : b.nb_spmv, nb_rz(b), ch, pq_rows, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, fold, qv, pq_clear));
     launch_cheb(A, k, step, b, nxt, s, folded);
 }
 
@@ -1756,8 +1762,11 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     double *cur = b.part_rz + (step & 1) * (kMaxPartialBlocks * 8);
     double *nxt = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<float> ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, b.nb_spmv, nb_rz(b), ch, b.part_pq, cur, nxt,
-                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>(), QViewT<float>()));
+    const bool bins = b.pq_bins && b.defer_q && A.patch && !pcg_update_folds(b);
+    const double *pq_rows = bins ? b.part_pq + (step & 1) * (kPqBins * 8) : b.part_pq;
+    double *pq_clear = bins ? b.part_pq + ((step + 1) & 1) * (kPqBins * 8) : nullptr;
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_update<float, KK>), dim3(g), dim3(256), 0, s, n, step, tol2, 1, bins ? kPqBins : b.nb_spmv, nb_rz(b), ch, pq_rows, cur, nxt,
+                                        b.rz0, b.progress, b.progress_len, b.p, b.q, b.x, b.r, b.dinv, FoldArgsT<float>(), QViewT<float>(), pq_clear));
     launch_mixed_accumulate(n * k, x64, b.x, 1, s);
     launch_spmm(A64, k, (const double *)x64, q64, (double *)nullptr, (const double *)nullptr, b.nb_spmv, s, 0);
     REMO_K_SWITCH(k, hipLaunchKernelGGL((k_mixed_replace<KK>), dim3(g), dim3(256), 0, s, n, ch.nv, f64, q64, b.r, b.dinv, nxt, b.rz0, step));

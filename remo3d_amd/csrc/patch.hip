@@ -199,7 +199,8 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
 // after it; the divergence chain hands every group of outputs to the LDS accumulators as soon as it is complete (no y[20]).
 template <class T, int K, int BLK, int MODE = 0, bool LEAN = false>
 __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
-                                                     double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps) {
+                                                     double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps,
+                                                     double *__restrict__ pbins) {
     if (scal && solve_done(scal, step)) return;
     // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
 #define REMO_STAMP(k) if constexpr (MODE == 4) { if (threadIdx.x == 0) stamps[(int64_t(blockIdx.x) << 3) + (k)] = __builtin_readcyclecounter(); }
@@ -418,7 +419,12 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
 #pragma unroll
         for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
         block_sum<K>(dot, smem);
-        if (tid < K) ppart[p * K + tid] = pick<K>(dot, tid);
+        if (tid < K) {
+            // pbins: straight into the consumer's rows (kPqBins of them, patches p, p + kPqBins, ... share one; return-less atomic
+            // adds performed at the memory side, complete when the launch ends) instead of a row per patch that a launch folds
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (p % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[p * K + tid] = pick<K>(dot, tid);
+        }
     }
     REMO_STAMP(7)
 #undef REMO_STAMP
@@ -562,9 +568,10 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     double *pp = part ? P.ppart : nullptr;
     const dim3 grid(int(per * 8));
     double *pp2 = pp;
+    double *bins = (part && defer && P.dot_bins) ? part + (step & 1) * (kPqBins * 8) : nullptr;
     auto launch = [&](auto kernel, int blk) {
         const size_t bytes = patch_lds_bytes(P.lds_rows, K, blk);   // staged rows, later fp64 accumulators + the two (padded) row tables
-        hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps);
+        hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
     if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
@@ -588,6 +595,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         else if (g_patch_lean == 1 || (g_patch_lean < 0 && sizeof(T) == 4)) launch(k_patch_apply<T, K, 256, 0, true>, 256);
         else launch(k_patch_apply<T, K, 256, 0>, 256);
     }
+    if (bins) return;     // the patches have added their sums into the update launch's rows themselves
     if (part && defer) {
         // (a few workgroups: the rows of `part` behind them stay zero - cleared by the solver once per solve)
         hipLaunchKernelGGL(k_patch_dot<K>, dim3(nb < kPatchDotBlocks ? nb : kPatchDotBlocks), dim3(256), 0, s, tb.npatch, (const double *)P.ppart, part, scal, step);

@@ -148,6 +148,7 @@ int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the mu
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 inline bool g_auto_patch_ok(int op);
 int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
+int g_dot_bins = 1;   // key 28: 1 = the patches add their <p, A p> straight into the update launch's rows (default), 0 = a row per patch + k_patch_dot
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
 int g_auto_patch = 1; // key 20: 1 = op 0 takes the patch operator in 3D whenever its tables fit (default), 0 = the round-2 choice by size
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
@@ -792,6 +793,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.nb_spmv = spmv_grid(n, lpr);
         buf.nb_vec = vec_grid(n);
         buf.defer_q = patch_op && g_defer_q && !pcg_update_folds(buf);     // the update launch sums the shared rows of q = A p itself
+        buf.pq_bins = buf.defer_q && g_dot_bins != 0;
+        if (patch_op) b->patch64.dot_bins = buf.pq_bins;
         const bool mixed = (o.precision == 1);
         MixedBuffers mx;
         if (mixed) {   // fp32 images of the system for the inner solver
@@ -835,6 +838,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             }
         }
         if (mixed) mx.b32.defer_q = patch_op && g_defer_q && !pcg_update_folds(mx.b32);
+        if (mixed) { mx.b32.pq_bins = mx.b32.defer_q && g_dot_bins; if (patch_op) b->patch32.dot_bins = mx.b32.pq_bins; }
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
         size_t ev_used = 0;
@@ -1397,6 +1401,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 24) g_ell = value;
     else if (key == 26) set_patch_lean(value);
     else if (key == 27) set_slab_ahead(value);
+    else if (key == 28) g_dot_bins = value;
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

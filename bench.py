@@ -431,7 +431,7 @@ def roofline_of(agg, precision, stride, workload_name=None):
     prec = "fp64" if precision == "fp64" else "fp32 values and vectors"
     kernel = {"csr": "k_spmm_pair (CSR SpMM, %s, k=5 interleaved RHS)",
               "element": "k_elem_apply + k_elem_reduce (element-wise operator with a slab of element results, %s; `achieved` prices the CSR product's bytes)",
-              "patch": "k_patch_apply + k_patch_reduce (matrix-free patch operator, %s, k=5 interleaved RHS; both launches inside the bracket)"}[op] % prec
+              "patch": "k_patch_apply (matrix-free patch operator, %s, k=5 interleaved RHS; inside the PCG the rows shared by several patches are summed by the update launch and <p, A p> is added by the patches themselves: one launch per application)"}[op] % prec
     fp = precision == "fp64"
     formula = {"csr": "12*nnz + 4*n + 16*k*n (SURVEY.md 8d)" if fp else "8*nnz + 4*n + 8*k*n (SURVEY.md 8d, fp32 storage)",
                "element": "12*nnz + 4*n + 16*k*n (the CSR product's figure)" if fp else "8*nnz + 4*n + 8*k*n",

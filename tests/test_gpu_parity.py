@@ -412,11 +412,14 @@ def test_chebyshev_launch_folds_keep_the_preconditioner(precision, mesh3d, gpu_c
                 rc = b.run(solver.make_opts(rtol=1e-10, coarse_degree=degree, coarse_ratio=30, precision=precision))
                 assert rc == 0
                 res[fold] = (np.concatenate(b.fetch()), b.stats["pcg_steps"])
-            assert np.allclose(res[0][0], res[1][0], rtol=1e-8, atol=0), degree
-            assert abs(res[0][1] - res[1][1]) <= max(2, res[0][1] // 50), (degree, res[0][1], res[1][1])
+            # (the patch operator sums in an order that varies from run to run - LDS and <p, A p> atomics: two fp64 solves agree
+            # to 1e-11, two solves of the mixed mode, whose refinement cycles end on a threshold, to a few 1e-8)
+            tol = 1e-8 if precision == "fp64" else 3e-7
+            assert np.allclose(res[0][0], res[1][0], rtol=tol, atol=0), degree
+            assert abs(res[0][1] - res[1][1]) <= max(2, res[0][1] // (50 if precision == "fp64" else 20)), (degree, res[0][1], res[1][1])
             if ref is None:
                 ref = res[1][0]
-            assert np.allclose(res[1][0], ref, rtol=1e-7, atol=0), degree
+            assert np.allclose(res[1][0], ref, rtol=max(tol, 1e-7), atol=0), degree
     finally:
         L.remo_debug_tune(9, 1)
         b.close()

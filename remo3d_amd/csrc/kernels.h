@@ -89,6 +89,7 @@ struct PatchTables {
     int E = 0;                         // elements per patch = block / right-hand sides of the batch (one lane per element and column)
     int rows_cap = 0;                  // rows of prow / pout per patch
     int block = 256;                   // threads per workgroup the tables were laid out for (256 or 512)
+    int spread = 1;                    // 1: the lanes of a wave take their elements from four runs of the patch's list (k_patch_apply)
     const uint16_t *lidx = nullptr;    // [nt][20] local row of every element dof inside its patch, 0xFFFF = constrained
     const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
     const int32_t *prow = nullptr;     // [npatch][rows_cap] matrix row of local row m, ascending
@@ -155,6 +156,7 @@ template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the upda
 void set_patch_mode(int mode);
 void set_patch_block(int threads);   // 256 (default) or 512
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
+void set_patch_spread(int v);
 void set_patch_lean(int v);          // register-lean arithmetic phase of the patch kernel: -1 fp32 only (default), 0 never, 1 always
 void set_patch_slab_rows(int v);     // 1: boundary slab row-major (0: patch-major)
 void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps

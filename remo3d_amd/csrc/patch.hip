@@ -224,7 +224,14 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     const int32_t *prow = tb.prow + p * tb.rows_cap, *pout = tb.pout + p * tb.rows_cap;
     const int el = tid / NL, c0 = tid - el * NL;
     const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);   // or-ed into a row number: negative = no row for this lane
-    const int64_t e = p * tb.E + el;
+    // the elements of a wave are taken from four runs of the patch's list instead of one (remo_debug_tune key 32: 0 = one run):
+    // consecutive elements of the sorted list share their smallest vertices, i.e. they add into the same LDS rows in the same
+    // instruction, which serialises - application 138.0 / 125.4 us against 141.3 / 128.2 at 443 k / 424 k tetrahedra.  Lane group el
+    // takes element number (el >> 2) of run (el & 3); the runs have ceil((E - r) / 4) elements.
+    const int n0 = (tb.E + 3) >> 2, n1 = (tb.E + 2) >> 2, n2 = (tb.E + 1) >> 2;
+    const int run = el & 3;
+    const int elp = tb.spread ? ((run > 0 ? n0 : 0) + (run > 1 ? n1 : 0) + (run > 2 ? n2 : 0) + (el >> 2)) : el;
+    const int64_t e = p * tb.E + elp;
     const bool active = el < tb.E && e < tb.nt;
     uint32_t li[10];
     double cm[6];
@@ -502,6 +509,8 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 // fp64 96 registers with spills and five waves against 124 and four: 160 against 156 us), 0 = never, 1 = always
 int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
+int g_patch_spread = 1;
+void set_patch_spread(int v) { g_patch_spread = v; }
 int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
 void set_patch_slab_rows(int v) { g_patch_slab_rows = v ? 1 : 0; }
 int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
@@ -528,7 +537,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     if (rows_cap > E * 20) rows_cap = E * 20;
     int npad = 256;
     while (npad < E * 20) npad <<= 1;
-    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap; out.block = g_patch_block;
+    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap; out.block = g_patch_block; out.spread = g_patch_spread;
     out.npatch = (nt + E - 1) / E;
     out.C = C;
     uint16_t *lidx = ar.lo<uint16_t>(size_t(nt) * 20 + 8);

@@ -53,8 +53,8 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  * (measured slower); 24: 0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image; 26: register-lean order
  * of the patch kernel's arithmetic phase: -1 in fp32 storage only (default), 0 never, 1 always; 27: 0 = slab slots of a shared row
  * fetched one by one in the update launch (default 1: four in flight); 28: 0 = the patches leave a row of <p, A p> each and a launch
- * folds them (default 1: atomic adds into the update launch's rows); 32: 0 = the lanes of a wave of the patch kernel take consecutive
- * elements (default 1: from four runs of the patch's list).  Process-global. */
+ * folds them (default 1: atomic adds into the update launch's rows); 32: number of runs of the patch's list from which the lanes of a wave of the
+ * patch kernel take their elements (default 4; 0 / 1: consecutive elements).  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -89,7 +89,7 @@ struct PatchTables {
     int E = 0;                         // elements per patch = block / right-hand sides of the batch (one lane per element and column)
     int rows_cap = 0;                  // rows of prow / pout per patch
     int block = 256;                   // threads per workgroup the tables were laid out for (256 or 512)
-    int spread = 1;                    // 1: the lanes of a wave take their elements from four runs of the patch's list (k_patch_apply)
+    int spread = 4;                    // the lanes of a wave take their elements from this many runs of the patch's list (k_patch_apply; <= 1: one run)
     const uint16_t *lidx = nullptr;    // [nt][20] local row of every element dof inside its patch, 0xFFFF = constrained
     const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
     const int32_t *prow = nullptr;     // [npatch][rows_cap] matrix row of local row m, ascending

@@ -228,9 +228,11 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // consecutive elements of the sorted list share their smallest vertices, i.e. they add into the same LDS rows in the same
     // instruction, which serialises - application 138.0 / 125.4 us against 141.3 / 128.2 at 443 k / 424 k tetrahedra.  Lane group el
     // takes element number (el >> 2) of run (el & 3); the runs have ceil((E - r) / 4) elements.
-    const int n0 = (tb.E + 3) >> 2, n1 = (tb.E + 2) >> 2, n2 = (tb.E + 1) >> 2;
-    const int run = el & 3;
-    const int elp = tb.spread ? ((run > 0 ? n0 : 0) + (run > 1 ? n1 : 0) + (run > 2 ? n2 : 0) + (el >> 2)) : el;
+    // (R runs: lane group el takes element el / R of run el % R; run r has ceil((E - r) / R) elements and starts behind the runs before it:
+    //  r * floor(E / R) + min(r, E % R))
+    const int R = tb.spread > 1 ? tb.spread : 1;
+    const int run = el % R, base = tb.E / R, extra = tb.E % R;
+    const int elp = R > 1 ? (run * base + (run < extra ? run : extra) + el / R) : el;
     const int64_t e = p * tb.E + elp;
     const bool active = el < tb.E && e < tb.nt;
     uint32_t li[10];
@@ -509,7 +511,7 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 // fp64 96 registers with spills and five waves against 124 and four: 160 against 156 us), 0 = never, 1 = always
 int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
-int g_patch_spread = 1;
+int g_patch_spread = 4;
 void set_patch_spread(int v) { g_patch_spread = v; }
 int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
 void set_patch_slab_rows(int v) { g_patch_slab_rows = v ? 1 : 0; }

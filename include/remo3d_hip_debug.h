@@ -54,7 +54,8 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  * of the patch kernel's arithmetic phase: -1 in fp32 storage only (default), 0 never, 1 always; 27: 0 = slab slots of a shared row
  * fetched one by one in the update launch (default 1: four in flight); 28: 0 = the patches leave a row of <p, A p> each and a launch
  * folds them (default 1: atomic adds into the update launch's rows); 32: number of runs of the patch's list from which the lanes of a wave of the
- * patch kernel take their elements (default 4; 0 / 1: consecutive elements).  Process-global. */
+ * patch kernel take their elements (default 4; 0 / 1: consecutive elements); 33: 0 = every workgroup of the patch kernel walks
+ * the largest patch's row count in its staging and output phases (default 1: its own patch's).  Process-global. */
 void remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -89,6 +89,7 @@ struct PatchTables {
     int E = 0;                         // elements per patch = block / right-hand sides of the batch (one lane per element and column)
     int rows_cap = 0;                  // rows of prow / pout per patch
     int block = 256;                   // threads per workgroup the tables were laid out for (256 or 512)
+    int trim = 1;                      // 1: a workgroup's staging / output phases stop at its own patch's row count
     int spread = 4;                    // the lanes of a wave take their elements from this many runs of the patch's list (k_patch_apply; <= 1: one run)
     const uint16_t *lidx = nullptr;    // [nt][20] local row of every element dof inside its patch, 0xFFFF = constrained
     const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
@@ -106,7 +107,10 @@ template <class T> struct PatchOpT {
     int lds_rows = 0;                  // largest pcount: sizes the kernel's LDS
     bool dot_bins = false;             // PcgBuffersT::pq_bins of the solve that applies it
 };
-constexpr int kPatchPasses = 12;   // staging passes a lane's registers hold (k_patch_apply)
+#ifndef REMO_PATCH_PASSES
+#define REMO_PATCH_PASSES 12
+#endif
+constexpr int kPatchPasses = REMO_PATCH_PASSES;   // staging passes a lane's registers hold (k_patch_apply)
 // dynamic LDS of k_patch_apply: staged k-wide rows (later the fp64 accumulators; + the zero row and one of slack) and the two
 // row tables padded to whole staging passes; a workgroup may ask for 64 KB less the kernel's static 128 k bytes
 inline size_t patch_lds_bytes(int lds_rows, int k, int block) {
@@ -156,6 +160,7 @@ template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the upda
 void set_patch_mode(int mode);
 void set_patch_block(int threads);   // 256 (default) or 512
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
+void set_patch_trim(int v);
 void set_patch_spread(int v);
 void set_patch_lean(int v);          // register-lean arithmetic phase of the patch kernel: -1 fp32 only (default), 0 never, 1 always
 void set_patch_slab_rows(int v);     // 1: boundary slab row-major (0: patch-major)

@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "kutil.h"
 #include "patch.h"
+#include <type_traits>
 #include "symbolic_gpu.h"
 #include "wave_util.h"
 
@@ -222,6 +223,13 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     const int64_t p = int64_t(blockIdx.x & 7) * per + int64_t(blockIdx.x >> 3);
     if (p >= tb.npatch) return;
     const int32_t *prow = tb.prow + p * tb.rows_cap, *pout = tb.pout + p * tb.rows_cap;
+    // the staging and output phases walk THIS patch's rows, not the largest patch's (`rows`: it sizes LDS and names the zero row): the
+    // average patch has 0.6 of the rows of the largest, and a pass without rows still cost its instructions.  The number of passes
+    // is a compile-time constant of the code that runs (a switch over 1 .. U: guards inside one unrolled loop keep the loads from
+    // going out together and cost what the shorter walk saves); remo_debug_tune key 33 = 0: the largest patch's count for all
+    const int rows_own = tb.pcount[p];
+    const int rows_p = (tb.trim && rows_own < rows) ? rows_own : rows;
+    const int npass = (rows_p + EK - 1) / EK;
     const int el = tid / NL, c0 = tid - el * NL;
     const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);   // or-ed into a row number: negative = no row for this lane
     // the elements of a wave are taken from four runs of the patch's list instead of one (remo_debug_tune key 32: 0 = one run):
@@ -278,17 +286,31 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // 24-bit multiplies: rows and slots are below 2^24 (checked by the caller).  Row `rows` is the zero row constrained dofs read.
     const rsrc_t rx = make_rsrc(x, uint64_t(tb.n) * K * S);
     const uint32_t slack = uint32_t((rows + 1) * K + c0);
-    for (int m0 = 0; m0 < rows; m0 += U * EK) {
-        int32_t r[U];
-        T v[U][1];
+    auto stage = [&](auto np_c, int m0) {
+        constexpr int NP = decltype(np_c)::value;
+        int32_t r[NP];
+        T v[NP][1];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = trow[m0 + el + EK * u] | off_mask;     // lanes beyond the last whole row of a pass: no row
+        for (int u = 0; u < NP; ++u) r[u] = trow[m0 + el + EK * u] | off_mask;     // lanes beyond the last whole row of a pass: no row
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < NP; ++u)
             buf_load<T, 1>(rx, r[u] >= 0 ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) xs[r[u] >= 0 ? uint32_t((m0 + el + EK * u) * K + c0) : slack] = v[u][0];
+        for (int u = 0; u < NP; ++u) xs[r[u] >= 0 ? uint32_t((m0 + el + EK * u) * K + c0) : slack] = v[u][0];
+    };
+#define REMO_PASSES(fn)                                                                                                   \
+    switch (npass) {                                                                                                      \
+        case 1: fn(std::integral_constant<int, 1>{}, 0); break;   case 2: fn(std::integral_constant<int, 2>{}, 0); break;   \
+        case 3: fn(std::integral_constant<int, 3>{}, 0); break;   case 4: fn(std::integral_constant<int, 4>{}, 0); break;   \
+        case 5: fn(std::integral_constant<int, 5>{}, 0); break;   case 6: fn(std::integral_constant<int, 6>{}, 0); break;   \
+        case 7: fn(std::integral_constant<int, 7>{}, 0); break;   case 8: fn(std::integral_constant<int, 8>{}, 0); break;   \
+        case 9: fn(std::integral_constant<int, 9>{}, 0); break;   case 10: fn(std::integral_constant<int, 10>{}, 0); break; \
+        case 11: fn(std::integral_constant<int, 11>{}, 0); break; case 12: fn(std::integral_constant<int, 12>{}, 0); break; \
+        default:                                                                                                          \
+            for (int m0 = 0; m0 < rows_p; m0 += U * EK) fn(std::integral_constant<int, U>{}, m0);                         \
     }
+    static_assert(U == 12, "REMO_PASSES lists the cases 1 .. U");
+    REMO_PASSES(stage)
     if (tid < 2 * K) xs[rows * K + tid] = T(0);
     __syncthreads();
     REMO_STAMP(2)
@@ -321,7 +343,8 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
         }
         __syncthreads();    // every lane has read its x values: the staging area becomes the accumulators
         REMO_STAMP(3)
-        for (int j = tid; j < (rows + 1) * K; j += BLK) ya[j] = 0.0;
+        for (int j = tid; j < rows_p * K; j += BLK) ya[j] = 0.0;
+        if (tid < K) ya[rows * K + tid] = 0.0;
         __syncthreads();
         REMO_STAMP(4)
         if (active) {
@@ -357,7 +380,8 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     REMO_STAMP(3)
     // the accumulators are fp64 whatever T is: ds_add_f32 runs at about a lane per clock on this chip (measured: 204 of the 304 us
     // of the fp32 kernel at 443 k tetrahedra were its 20 atomics per lane; ds_add_f64 costs 4 us there)
-    for (int j = tid; j < (rows + 1) * K; j += BLK) ya[j] = 0.0;
+    for (int j = tid; j < rows_p * K; j += BLK) ya[j] = 0.0;
+    if (tid < K) ya[rows * K + tid] = 0.0;
     __syncthreads();
     REMO_STAMP(4)
     if (active) {
@@ -405,22 +429,24 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // 3. rows of this patch alone -> y; shared rows -> the patch's block of the boundary slab; one value per lane and pass again
     if constexpr (MODE != 3) {
         const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
-        for (int m0 = 0; m0 < rows; m0 += U * EK) {
-            int32_t r[U], o[U];
-            T v[U][1];
+        auto put = [&](auto np_c, int m0) {
+            constexpr int NP = decltype(np_c)::value;
+            int32_t r[NP], o[NP];
+            T v[NP][1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 const int m = m0 + el + EK * u;
                 r[u] = trow[m] | off_mask; o[u] = tout[m];
                 v[u][0] = T(ya[m * K + c0]);    // (behind the staged rows: whatever LDS holds, never stored)
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {       // one of the two stores of a value is out of range: dropped by the hardware, no branch
+            for (int u = 0; u < NP; ++u) {      // one of the two stores of a value is out of range: dropped by the hardware, no branch
                 const bool have = r[u] >= 0;
                 buf_store<T, 1>(ry, (have && o[u] < 0) ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
                 buf_store<T, 1>(rb, (have && o[u] >= 0) ? __umul24(uint32_t(o[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
             }
-        }
+        };
+        REMO_PASSES(put)
     }
     REMO_STAMP(6)
     if (ppart) {
@@ -437,6 +463,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     }
     REMO_STAMP(7)
 #undef REMO_STAMP
+#undef REMO_PASSES
 }
 
 // Rows shared by several patches: sum of the row's slab slots in ascending patch order.  DOT: the patches' <x, A x> are folded
@@ -511,6 +538,8 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 // fp64 96 registers with spills and five waves against 124 and four: 160 against 156 us), 0 = never, 1 = always
 int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
+int g_patch_trim = 1;
+void set_patch_trim(int v) { g_patch_trim = v; }
 int g_patch_spread = 4;
 void set_patch_spread(int v) { g_patch_spread = v; }
 int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
@@ -539,7 +568,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     if (rows_cap > E * 20) rows_cap = E * 20;
     int npad = 256;
     while (npad < E * 20) npad <<= 1;
-    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap; out.block = g_patch_block; out.spread = g_patch_spread;
+    out.nt = nt; out.n = n; out.E = E; out.rows_cap = rows_cap; out.block = g_patch_block; out.spread = g_patch_spread; out.trim = g_patch_trim;
     out.npatch = (nt + E - 1) / E;
     out.C = C;
     uint16_t *lidx = ar.lo<uint16_t>(size_t(nt) * 20 + 8);

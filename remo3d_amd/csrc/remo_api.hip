@@ -1403,6 +1403,7 @@ void remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 27) set_slab_ahead(value);
     else if (key == 28) g_dot_bins = value;
     else if (key == 32) set_patch_spread(value);
+    else if (key == 33) set_patch_trim(value);
     else if (key == 9) set_fold_first(value);
     else if (key == 13) g_compact = value;
     else if (key == 15) g_chain32 = value;

@@ -249,19 +249,23 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     for (int q = 0; q < 10; ++q) li[q] = 0u;
 #pragma unroll
     for (int q = 0; q < 6; ++q) cm[q] = 0.0;
-    if (active) {
-        const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);   // 40-byte records: 8-byte aligned
-#pragma unroll
-        for (int q = 0; q < 10; ++q) li[q] = pl[q];
-        if constexpr (!(LEAN && MODE != 2)) {
-            const double *ce = tb.C + e * 6;                           // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) cm[q] = ce[q];
-        }
-    }
     // 1a. the patch's row tables into LDS (one round trip; the output phase finds them there again).  prow holds -1 behind a
     // patch's last row, so no row count has to arrive first; the LDS copies are padded with -1 to whole passes of 1b.
-    for (int m0 = tid; m0 < rows_pad; m0 += 4 * BLK) {
+    // The table loads are issued BEFORE the element's own data (local rows, metric terms), which is wanted much later: loads
+    // return in order, and the wait in front of the LDS copies then covers the tables only.
+    auto element_data = [&]() {
+        if (active) {
+            const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);   // 40-byte records: 8-byte aligned
+#pragma unroll
+            for (int q = 0; q < 10; ++q) li[q] = pl[q];
+            if constexpr (!(LEAN && MODE != 2)) {
+                const double *ce = tb.C + e * 6;                           // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+            }
+        }
+    };
+    for (int m0 = tid; m0 < rows_pad || m0 == tid; m0 += 4 * BLK) {
         int32_t r[4], o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -269,6 +273,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
             r[u] = m < rows ? prow[m] : -1;
             o[u] = m < rows ? pout[m] : -1;
         }
+        if (m0 == tid) element_data();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int m = m0 + BLK * u;

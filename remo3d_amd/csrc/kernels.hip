@@ -961,6 +961,11 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         T qi[K];
         int32_t b0 = 0, b1 = 0;
         if (qv.bptr) { b0 = qv.bptr[i]; b1 = qv.bptr[i + 1]; }
+        // x, p and r of the row are requested HERE, with the row's slab pointers, not behind the branch that gathers q: three more
+        // vectors in flight while the slab slots make their two round trips
+        T xv[K], pv[K], rv[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) { xv[c] = x[i * K + c]; pv[c] = p[i * K + c]; rv[c] = r[i * K + c]; }
         if (b1 > b0) {      // a row shared by several patches: its q is still spread over the slab, one slot per patch, ascending
             // the first kSlabAhead slots without a branch and with all their loads in flight together (slot numbers, then slab
             // rows: two round trips; the plain loop made two per slot, and a wave waits for its row with the most slots) - a
@@ -999,8 +1004,8 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const T a = T(alpha[c]);
-            const T xi = x[i * K + c] + a * p[i * K + c];
-            const T ri = r[i * K + c] - a * qi[c];
+            const T xi = xv[c] + a * pv[c];
+            const T ri = rv[c] - a * qi[c];
             x[i * K + c] = xi;
             r[i * K + c] = ri;
             acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels

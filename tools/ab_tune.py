@@ -17,7 +17,7 @@ def main():
     from concurrent.futures import ProcessPoolExecutor
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     with ProcessPoolExecutor(max_workers=min(nb, 8), mp_context=multiprocessing.get_context("spawn")) as pool:   # before the GPU is touched
-        wl = bench.build_workload(0, 1, 20, bench.SIZES[size], max_batches=nb, pool=pool if nb > 1 else None)
+        wl = bench.build_workload(0, 1, int(kw.get("depths", 20)), bench.SIZES[size], max_batches=nb, pool=pool if nb > 1 else None)
     print("meshes done: T = %s" % [int(w["mesh"].n_elems) for w in wl["work"]], flush=True)
     from remo3d_amd import _lib, solver
     L = _lib.load()

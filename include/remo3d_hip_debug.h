@@ -51,7 +51,7 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  * operator wherever its tables fit); 21: ablation mode of the patch kernel (1 no LDS atomics, 2 no arithmetic, 3 no output: wrong
  * results on purpose); 22: 0 = shared rows summed by k_patch_reduce instead of the update launch; 23: 1 = boundary slab row-major
  * (measured slower); 24: 0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image; 26: register-lean order
- * of the patch kernel's arithmetic phase: -1 in fp32 storage only, 0 never (default), 1 always; 27: 0 = slab slots of a shared row
+ * of the patch kernel's arithmetic phase: -1 in fp32 storage only (default), 0 never, 1 always; 27: 0 = slab slots of a shared row
  * fetched one by one in the update launch (default 1: four in flight); 28: 0 = the patches leave a row of <p, A p> each and a launch
  * folds them (default 1: atomic adds into the update launch's rows); 32: number of runs of the patch's list from which the lanes of a wave of the
  * patch kernel take their elements (default 4; 0 / 1: consecutive elements); 33: 0 = every workgroup of the patch kernel walks

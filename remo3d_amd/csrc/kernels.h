@@ -162,7 +162,7 @@ void set_patch_block(int threads);   // 256 (default) or 512
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
 void set_patch_trim(int v);
 void set_patch_spread(int v);
-void set_patch_lean(int v);          // register-lean arithmetic phase of the patch kernel: -1 fp32 only, 0 never (default), 1 always
+void set_patch_lean(int v);          // register-lean arithmetic phase of the patch kernel: -1 fp32 only (default), 0 never, 1 always
 void set_patch_slab_rows(int v);     // 1: boundary slab row-major (0: patch-major)
 void set_patch_stamps(long long *device_buffer);   // mode 4: [workgroups][8] phase time stamps
 int patch_elements_per_group(int kmax);

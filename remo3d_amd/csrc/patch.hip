@@ -538,11 +538,12 @@ long long *g_patch_stamps = nullptr;   // mode 4: device buffer [grid][8] of pha
 void set_patch_mode(int mode) { g_patch_mode = mode; }
 void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 
-// remo_debug_tune key 26: the register-lean order of the kernel's arithmetic phase (k_patch_apply LEAN): -1 = in fp32 storage only, 0 =
-// never (default), 1 = always.  It was the fp32 default for a day (72 registers and seven waves per SIMD against 104 and four: 111
-// against 124 us) until the staging / output phases got their pass count as a compile-time constant: the plain order then needs
-// 67 registers by itself (seven waves) and runs 87 against 90 us.  fp64: 96 registers with spills, five waves: 160 against 156 us.
-int g_patch_lean = 0;
+// remo_debug_tune key 26: the register-lean order of the kernel's arithmetic phase (k_patch_apply LEAN): -1 = in fp32 storage only
+// (default), 0 = never, 1 = always.  fp32: 72-80 registers against 104 at first (111 against 124 us at 443 k tetrahedra); once the
+// staging / output phases had their pass count as a compile-time constant the plain order needed 67 registers by itself and was
+// level at 443 k tetrahedra (87 against 90 us) but not on the batches of the headline sweep (370 k / 320 k: 86 against 77 us, solve
+// 158.3 against 153.1 ms per four batches): lean stays the fp32 default.  fp64: 96 registers with spills, five waves: 160 against 156 us.
+int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
 int g_patch_trim = 1;
 void set_patch_trim(int v) { g_patch_trim = v; }

@@ -425,6 +425,87 @@ def make_mesh(dim: int, R: float = 50.0, sources_z: Sequence[float] = (0.0,), sc
 
 
 # ---------------------------------------------------------------------------------------------
+# on-disk cache of generated meshes
+#
+# A lattice mesh depends on the electrode pattern of a batch in the batch-centred frame, the size multiplier and the seed -
+# not on the depth: the 40 batches of the bench's sweep use TWO distinct meshes (one per tool), and so do all ranks of a
+# multi-GPU run, all legs of one bench run and a rerun.  A size-L mesh takes 17-22 s of one core, so the meshes are kept as
+# .npz files keyed by a hash of those arguments (and of this file, so that a change of the mesher invalidates them).
+# One process builds, the others wait on the file's lock and load.  REMO_MESH_CACHE = directory (default: a per-user directory
+# under /dev/shm, else the temporary directory), "0" = no cache.
+
+_CODE_TAG = None
+
+
+def mesh_cache_dir() -> Optional[str]:
+    import os
+    import tempfile
+    d = os.environ.get("REMO_MESH_CACHE")
+    if d in ("0", ""):
+        return None
+    if d is None:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        d = os.path.join(base, "remo3d_mesh_cache_%d" % os.getuid())
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return None
+    return d
+
+
+def cached_mesh(key: tuple, build: Callable[[], Mesh]) -> Mesh:
+    """build() through the on-disk cache: key = everything the mesh depends on (plain numbers / tuples)."""
+    import hashlib
+    import os
+    global _CODE_TAG
+    d = mesh_cache_dir()
+    if d is None:
+        return build()
+    if _CODE_TAG is None:
+        with open(__file__, "rb") as f:
+            _CODE_TAG = hashlib.sha1(f.read()).hexdigest()[:12]
+    name = hashlib.sha1(repr((key, _CODE_TAG, np.__version__)).encode()).hexdigest()[:24]
+    path = os.path.join(d, name + ".npz")
+
+    def load():
+        with np.load(path, allow_pickle=False) as z:
+            meta = {k[5:]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("meta_")}
+            if "sources_z" in meta:
+                meta["sources_z"] = [float(v) for v in np.atleast_1d(meta["sources_z"])]
+            return Mesh(int(z["dim"]), z["coords"], z["conn"], z["mat"], z["bconn"], z["bdirichlet"], meta)
+
+    if os.path.exists(path):
+        try:
+            return load()
+        except Exception:
+            pass                     # unreadable (e.g. a crashed writer of an older layout): rebuild below
+    try:
+        import fcntl
+        lock = open(path + ".lock", "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)      # the first process builds, the others wait here and find the file
+    except Exception:
+        lock = None
+    try:
+        if os.path.exists(path):
+            try:
+                return load()
+            except Exception:
+                pass
+        mesh = build()
+        try:
+            tmp = "%s.%d.tmp.npz" % (path, os.getpid())
+            meta = {"meta_" + k: np.asarray(v) for k, v in mesh.meta.items() if isinstance(v, (int, float, list, tuple, np.ndarray, np.generic))}
+            np.savez(tmp, dim=np.int64(mesh.dim), coords=mesh.coords, conn=mesh.conn, mat=mesh.mat, bconn=mesh.bconn, bdirichlet=mesh.bdirichlet, **meta)
+            os.replace(tmp, path)
+        except OSError:
+            pass                     # a full or read-only cache directory is not an error
+        return mesh
+    finally:
+        if lock is not None:
+            lock.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # material models (centroid classification) for the reference's benchmark inputs
 
 

@@ -34,6 +34,22 @@ CONVERSION = {"M": 1.0, "DM": 0.1, "CM": 0.01, "MM": 0.001, "IN": 0.0254, "FT": 
 DEFAULT_SCALE = {2: 0.35, 3: 1.0}
 
 
+def lattice_mesh_key(dim, domain_radius, batch, scale, seed=0) -> tuple:
+    """What a lattice mesh depends on: the electrode pattern of the batch in its own frame, size multiplier and seed - not the
+    depth (the 40 batches of the bench's 100-depth sweep share six meshes).  Key of the provider's caches, in memory and on disk."""
+    cur = batch.electrodes[0, batch.electrodes[1, :] != 0]
+    pot = batch.electrodes[0, batch.electrodes[1, :] == 0]
+    return (int(dim), float(domain_radius), tuple(float(v) for v in np.round(cur, 4)), tuple(float(v) for v in np.round(pot, 4)), float(scale), int(seed))
+
+
+def tuned_coarse_for_conforming(n_nodes: int) -> dict:
+    """Chebyshev degree / interval of the P1 block for the revolved conforming 3D meshes: graded and sheared, they want a higher
+    degree and a wider interval than the library's default for isotropic meshes of the same vertex count (GPU scan,
+    tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)."""
+    rel = max(int(n_nodes), 1) / 12600.0
+    return dict(coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))), coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
+
+
 def default_mesh_provider(scale: Optional[float] = None, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
     """Batch mesh factory.  scale: multiplier on the reference's size field (None: DEFAULT_SCALE by dimension).  2D: interface-conforming half-disc meshes built per batch.
     3D, mesh_3d = "conforming" (default): the 2D conforming mesh of the window revolved in the sheared
@@ -69,11 +85,12 @@ def default_mesh_provider(scale: Optional[float] = None, seed: int = 0, mesh_3d:
             cap = meshgen.LayerCap(np.concatenate([fg[:1, 0], fg[:, 1]]))
             return meshgen.make_mesh_3d_conforming(domain_radius, local_formation_geometry, local_borehole_geometry, dip_rad,
                                                    sources_z=list(cur), snap_z=list(pot), scale=scale, seed=seed, layer_cap=cap, sectors=sectors)
-        key = (dim, float(domain_radius), tuple(np.round(cur, 4)), tuple(np.round(pot, 4)), float(scale), seed)
+        key = lattice_mesh_key(dim, domain_radius, batch, scale, seed)
         base = cache.get(key)
         if base is None:
-            base = meshgen.make_mesh(dim, domain_radius, sources_z=list(cur), scale=scale, seed=seed,
-                                     snap_z=[z for z in pot if abs(z) < domain_radius])
+            # (also kept on disk, meshgen.cached_mesh: every batch of a tool, every rank and every rerun share it)
+            base = meshgen.cached_mesh(("lattice",) + key, lambda: meshgen.make_mesh(
+                dim, domain_radius, sources_z=list(cur), scale=scale, seed=seed, snap_z=[z for z in pot if abs(z) < domain_radius]))
             if len(cache) > 64:
                 cache.clear()
             cache[key] = base
@@ -224,7 +241,7 @@ class Model:
     # -- workers (remo3d.py:552-599, 887-899) ------------------------------------------------------
     def initialize_workers(self, cpu_workers=4, gpu_workers=0, context_factory: Optional[Callable] = None):
         """The reference spawns MPI workers here (remo3d.py:552-599); this build opens GPU contexts in the
-        calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (at least one), each
+        calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (0, the default, = two), each
         with its own HIP stream and arena and driven by its own host thread in simulate_logs, so batches
         overlap on the GPU the way the reference's GPU workers overlap (two fill the launch-latency gaps of
         one: +15 % in 3D, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
@@ -245,7 +262,11 @@ class Model:
         device = int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         make = context_factory or solver.Context     # context_factory(device): a stand-in solver for the CPU tests of the sweep
         self.ctx = make(device)
-        self.extra_ctx = [make(device) for _ in range(max(0, min(gpu_workers, 4) - 1))]
+        # contexts on this GPU: gpu_workers of them (at most 4); the reference's default gpu_workers = 0 means "no GPU worker"
+        # there and "the build's default" here: TWO contexts - the launch-latency-bound quarter of one batch's PCG step (the chain
+        # of small launches on the vertex block) is filled by the other batch's kernels: +16 % points/s in 3D, more in 2D
+        n_ctx = 2 if gpu_workers == 0 else min(gpu_workers, 4)
+        self.extra_ctx = [make(device) for _ in range(n_ctx - 1)]
 
     def shutdown_workers(self):
         for c in getattr(self, "extra_ctx", []):
@@ -298,8 +319,14 @@ class Model:
         mud = np.interp(simulation_depths, self.borehole_model[:, 0], self.borehole_model[:, 2])
         if verbose and sweep.rank() == 0:
             print("{} simulation tasks prepared".format(len(batches)))
-        opts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision, **extra)
-        tuned_coarse = mesh_provider is None and preconditioner == "multigrid"     # the default 3D provider = conforming revolved meshes
+        # ONE dictionary of solver keywords: the explicit arguments, over-ridden by solver_options (a key given in both places used
+        # to raise "multiple values" inside every batch, i.e. a sweep of NaNs); unknown keys fail here, before any batch is drawn,
+        # on every rank alike
+        base_kw = dict(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision)
+        base_kw.update(extra)
+        opts = solver.make_opts(**base_kw)
+        tuned_coarse = (mesh_provider is None and base_kw["preconditioner"] == "multigrid"
+                        and "coarse_degree" not in extra and "coarse_ratio" not in extra)     # the default 3D provider = conforming revolved meshes
 
         n_tools = len(self.tools)
         results = np.zeros((len(measurement_depths), n_tools))
@@ -398,13 +425,7 @@ class Model:
                 t1 = time.time()
                 bopts = opts
                 if tuned_coarse and mesh.dim == 3:
-                    # the revolved conforming meshes are graded and sheared: their P1 block wants a higher Chebyshev degree
-                    # and a wider interval than the library's default for isotropic meshes of the same vertex count
-                    # (GPU scan, tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)
-                    rel = max(mesh.n_nodes, 1) / 12600.0
-                    bopts = solver.make_opts(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision, **extra,
-                                             coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))),
-                                             coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
+                    bopts = solver.make_opts(**dict(base_kw, **tuned_coarse_for_conforming(mesh.n_nodes)))
                 c = free_ctx.get()
                 try:
                     outs, st, rc = c.solve_batch(mesh, sigma, sources, evals, bopts)

@@ -198,6 +198,13 @@ def _cpu_leg_main(path, idx):
         json.dump(dict(seconds=dt, rc=int(rc), iterations=st["iterations"], n=st.get("n"), out=[float(v) for v in out], batch=bi, rhs=k), f)
 
 
+def under_profiler():
+    """True when a rocprofv3 tool library is preloaded into this process: its GPU is initialised before main() runs, so no child
+    process may be started from it (bench.py and the tools build their meshes in-process then; the on-disk mesh cache, filled by an
+    un-profiled run of the same command, makes that a file read)."""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB"))
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -622,7 +629,7 @@ def main():
     import numpy as np
     strong = args.total_depths > 0
     dynamic = args.schedule == "dynamic" and world > 1
-    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB"))
+    profiled = under_profiler()
     extras = ((world == 1) and not args.no_extras and not args.resident and args.precision == "fp64" and args.mesh == "lattice" and not args.tune
               and args.op == "auto" and not args.coarse and not args.batches and not profiled)
     extra_specs = []

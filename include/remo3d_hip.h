@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define REMO_ABI_VERSION 6
+#define REMO_ABI_VERSION 7
 #define REMO_MAX_RHS 8 /* right-hand sides solved as one block; longer batches are chunked */
 
 #define REMO_OK 0
@@ -74,15 +74,15 @@ typedef struct {
                                several contexts driven by several host threads only ONE batch is in its PCG at any time while the
                                others number / assemble theirs beside it (software pipelining across batches); 0: no lock      */
     int32_t op;             /* how the CG applies A (CGSolver's a.mat, ngsolve_functions.py:50-51):
-                               3 = patch operator (3D only; 2D always uses the CSR product): matrix-free - the element list is cut
-                                   into patches of 256 / k tetrahedra, a workgroup stages the x rows of its patch in LDS, applies every
-                                   K_e through the factorised reference tensors and writes each row once (rows shared by patches through
-                                   a compact slab); same operator to rounding; results reproducible to rounding, not bit for bit (LDS
-                                   atomics) - the one kernel of the path for which that holds;
+                               3 = patch operator (3D; a 2D batch runs on the CSR product whatever this says): matrix-free - the element
+                                   list is cut into patches of 256 / k tetrahedra, a workgroup stages the x rows of its patch in LDS, applies
+                                   every K_e through the factorised reference tensors and writes each row once (rows shared by patches
+                                   through a compact slab); same operator to rounding; results reproducible to rounding, not bit for bit
+                                   (LDS atomics) - the one kernel of the path for which that holds;
                                2 = CSR SpMM on the assembled matrix (bit-reproducible);
-                               1 = element-wise with a slab of element results (round 2; kept for comparison);
-                               0 = default: 3 in 3D (at the reference's resolution an application takes 125 us against 372-450 us
+                               0 = default: 3 in 3D (at the reference's resolution an application takes ~100 us against 370-450 us
                                    of the CSR product and moves 0.4 GB instead of 1.25 GB), 2 in 2D.
+                               (1 was the round-2 element-wise operator with a slab of element results: removed with ABI 7, REMO_ERR_ARG.)
                                What is assembled: remo_opts_t.assemble */
     int32_t coarse;         /* "multigrid": the solver of the P1 (vertex) block.
                                1 = Chebyshev polynomial (coarse_degree, coarse_ratio);
@@ -98,7 +98,7 @@ typedef struct {
                                    2 M-row matrix are 4.5 ms of an 80 ms batch and 1.2 GB;
                                1 = always the whole matrix; 2 = diagonal + P1 block whenever the patch operator runs.
                                Without the matrix remo_batch_get_system (rowptr / col / val) and products with more columns than the
-                               batch has right-hand sides fail with REMO_ERR_ARG; op = 1 / 2 always assemble */
+                               batch has right-hand sides fail with REMO_ERR_ARG (remo_stats_t.assembled says which it was); op = 2 always assembles */
     int32_t quadrature;     /* 2D: how the reference tensors of `2 pi x sigma grad(u) grad(v)` (ngsolve_functions.py:34; a degree-5 integrand) are
                                integrated: 0 = exactly (default); 1 = by the 6-point rule that is exact to degree 4 - the alternative NGSolve
                                may be using (its rule order is not pinned by the reference).  3D integrands have degree 4: always exact */
@@ -122,14 +122,19 @@ typedef struct {
     double spmv_ms;      /* sum of the event-timed SpMV launches (time_kernels > 0), minus the bracket
                             overhead below per launch                                             */
     int64_t spmv_launches;
-    double spmv_bytes;   /* algorithmic bytes of ONE SpMV launch: 12 nnz + 4 n + 16 k n            */
+    double spmv_bytes;   /* algorithmic bytes of ONE operator application: CSR product 12 nnz + 4 n + 16 k n;
+                            patch operator 16 k n + 88 T (x read and y written once, 40 B of local indices + 48 B of
+                            metric terms per element); fp32 storage (mixed): 8 nnz + 4 n + 8 k n / 8 k n + 88 T        */
     int64_t pcg_steps;   /* total PCG steps executed on the device (incl. post-convergence slack)  */
     double spmv_ms_raw;  /* the same sum before the correction                                     */
     double event_overhead_ms; /* elapsed time of an EMPTY hipEvent pair on the stream (min of 16),
                             i.e. what a bracket measures beyond the kernel it encloses             */
     int64_t refinement_cycles; /* mixed precision: fp32 inner solves that contributed a correction (all chunks) */
-    int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 1 = element by element, 3 = patch operator (remo_opts_t.op) */
+    int32_t op_used;     /* 0 = the CG applied A as a CSR SpMM, 3 = patch operator (remo_opts_t.op) */
     int32_t coarse_used; /* vertex-block solver of the run: 0 = none ("local"), 1 = Chebyshev polynomial, 2 = multigrid cycle */
+    int32_t assembled;   /* 1 = the whole matrix, 2 = only the Jacobi diagonal and the P1 (vertex) block (remo_opts_t.assemble):
+                            then remo_batch_get_system hands out dinv / freeid only and nnz reads 0                  */
+    int32_t reserved_;
 } remo_stats_t;
 
 typedef struct remo_ctx remo_ctx_t;
@@ -209,8 +214,8 @@ int remo_batch_spmv(remo_ctx_t *ctx, remo_batch_t *batch, int32_t k, const doubl
  */
 int remo_host_element_matrix(int32_t dim, const double *vertex_coords /*[(dim+1)*dim], sorted vertices*/,
                              double sigma, double *K_out);
-/* max |sum_m B_a[m][i] B_b[m][j] - M_ab[i][j]|: how well the factorised reference tensors of the element-wise operator
- * (remo_opts_t.op = 1) reproduce the tensors the CSR assembly contracts (both exact polynomial integrals). */
+/* max |sum_m B_a[m][i] B_b[m][j] - M_ab[i][j]|: how well the factorised reference tensors of the patch operator
+ * (remo_opts_t.op = 3) reproduce the tensors the CSR assembly contracts (both exact polynomial integrals). */
 double remo_host_factor_error(void);
 int remo_host_symbolic(const remo_mesh_t *mesh, int32_t condense, int64_t *sizes /*[6]: n_dof,n_free,nnz,n_edges,n_faces,nld*/,
                        int32_t *rowptr /*[n_free+1] or NULL*/, int32_t *col /*[nnz] or NULL*/,

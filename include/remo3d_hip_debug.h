@@ -39,24 +39,30 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *batch, int32_t fp32 /
  * barrier, [1] = 1 if a wait gave up, [2] = loads that did not see the store. */
 int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, double *out3);
 
-/* Kernel tuning knob for the probe scripts (tools/probe_spmm.py): key 0 SpMM variant (1 lane per stored
- * entry, 3 edge row pairs = default), 1 lanes per row, 2 threads per workgroup, 3 row schedule of
- * the pair kernel (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; default by size), 4 grid size;
- * value 0 (mapping: -1) restores the default; 5 ablation mode of the pair kernel; 6: 0 = one launch per Chebyshev
- * step, 1 = paired steps on the squared vertex block in 2D (default), 2 = paired steps also in 3D; 7 lanes per row of the
- * paired kernel; 8: 0 = CSR pattern by the global sort instead of row by row; 9: 0 = first
- * Chebyshev step as a launch of its own instead of inside the update launch; 13: 0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always; 15: 0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage, the preconditioner may be inexact); 16: 1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides); 17: 0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage);
- * round 3: 18: 0 = elements taken in the caller's order (default 1: sorted by their two smallest vertices); 19: threads per workgroup of
- * the patch kernel, 256 (default) or 512; 20: 0 = op 0 chooses the operator by stored entries as in round 2 (default 1: the patch
- * operator wherever its tables fit); 21: ablation mode of the patch kernel (1 no LDS atomics, 2 no arithmetic, 3 no output: wrong
- * results on purpose); 22: 0 = shared rows summed by k_patch_reduce instead of the update launch; 23: 1 = boundary slab row-major
- * (measured slower); 24: 0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image; 26: register-lean order
- * of the patch kernel's arithmetic phase: -1 in fp32 storage only (default), 0 never, 1 always; 27: 0 = slab slots of a shared row
- * fetched one by one in the update launch (default 1: four in flight); 28: 0 = the patches leave a row of <p, A p> each and a launch
- * folds them (default 1: atomic adds into the update launch's rows); 32: number of runs of the patch's list from which the lanes of a wave of the
- * patch kernel take their elements (default 4; 0 / 1: consecutive elements); 33: 0 = every workgroup of the patch kernel walks
- * the largest patch's row count in its staging and output phases (default 1: its own patch's).  Process-global. */
-void remo_debug_tune(int32_t key, int32_t value);
+/* Process-global knobs, two kinds.  Returns 0, or -1 for a key this build does not have.
+ *
+ * (a) ALWAYS THERE - keys that force one of the product's own paths, i.e. a choice the library makes by size or dimension, so that
+ * a small test mesh reaches the code a large batch runs.  Every setting gives the same operator / preconditioner to rounding:
+ *    3  row schedule of the CSR product (0 grid-stride, 1 XCD windows, 16 * nc XCD regions of nc chunks; -1 = by size);
+ *    6  0 = one launch per Chebyshev step, 1 = paired steps on the squared vertex block in 2D (default), 2 = also in 3D;
+ *    9  0 = first Chebyshev step as a launch of its own instead of inside the update launch;
+ *   13  0 = Chebyshev launches read the vertex block inside A, 1 = from a compact copy above 16 k vertices (default), 2 = always;
+ *   15  0 = the Chebyshev chain of an fp64 solve stays in fp64 also above 32 k vertex rows (default there: fp32 storage), 2 = fp32 always;
+ *   16  1 = never the multigrid cycle on the vertex block, 2 = always, any dimension (0: remo_opts_t.coarse decides);
+ *   17  0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage);
+ *   18  0 = elements taken in the caller's order (default 1: sorted by their two smallest vertices);
+ *   22  0 = rows shared by patches summed by k_patch_reduce instead of the PCG's update launch;
+ *   24  0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image.
+ *
+ * (b) ONLY IN A LIBRARY BUILT WITH -DREMO_PROBES (`make -C remo3d_amd/csrc probes` -> libremo3d_hip_probes.so, loaded by the tools
+ * through REMO_LIB=...): rejected experiments and ablations, some of which give WRONG RESULTS ON PURPOSE.  The product ignores them:
+ *    0 SpMM variant, 1 lanes per row, 2 threads per workgroup, 4 grid size, 5 ablation mode of the pair kernel; 7 lanes per row of
+ *    the paired Chebyshev kernel; 8: 0 = CSR pattern by the global sort; 19 threads per workgroup of the patch kernel (512); 21 ablation
+ *    mode of the patch kernel (1 no LDS atomics, 2 no arithmetic, 3 no output); 23: 1 = boundary slab row-major; 26 register-lean order
+ *    of the patch kernel (0 never, 1 always; product: fp32 storage only); 27: 0 = slab slots of a shared row fetched one by one;
+ *    28: 0 = a row of <p, A p> per patch + a folding launch; 32 runs of the patch's list per wave (product: 4); 33: 0 = every
+ *    workgroup walks the largest patch's row count.  remo_debug_patch_phases and remo_debug_grid_barrier also need that build. */
+int remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

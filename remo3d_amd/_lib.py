@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libremo3d_hip.so")
+# REMO_LIB: another build of the same library (tools/: the -DREMO_PROBES build, compile-time variants); the product loads its own
+LIB_PATH = os.environ.get("REMO_LIB") or os.path.join(_HERE, "libremo3d_hip.so")
 REMO_MAX_RHS = 8
 
 
@@ -36,7 +37,8 @@ class RemoStats(C.Structure):
                 ("ms_solve", C.c_double), ("ms_eval", C.c_double), ("ms_total", C.c_double),
                 ("spmv_ms", C.c_double), ("spmv_launches", C.c_int64), ("spmv_bytes", C.c_double),
                 ("pcg_steps", C.c_int64), ("spmv_ms_raw", C.c_double), ("event_overhead_ms", C.c_double),
-                ("refinement_cycles", C.c_int64), ("op_used", C.c_int32), ("coarse_used", C.c_int32)]
+                ("refinement_cycles", C.c_int64), ("op_used", C.c_int32), ("coarse_used", C.c_int32),
+                ("assembled", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self):
         d = {}
@@ -114,6 +116,7 @@ def load():
     L.remo_host_factor_error.restype = C.c_double
     L.remo_host_symbolic.restype = C.c_int
     L.remo_host_symbolic.argtypes = [C.POINTER(RemoMesh), C.c_int32, i64p, ip, ip, ip]
+    L.remo_debug_tune.restype = C.c_int
     L.remo_debug_tune.argtypes = [C.c_int32, C.c_int32]
     _lib = L
     return L

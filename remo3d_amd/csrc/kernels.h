@@ -70,19 +70,6 @@ constexpr int kPqBins = 256;       // rows of a set of <p, A p> bins (PcgBuffers
 constexpr int kScalarSlots = 48;   // doubles behind PcgBuffersT::rz0
 constexpr int kDoneSlot = 4 * 8;   // rz0[kDoneSlot] (as int): step + 1 of the update launch that froze every column (kernels.hip solve_done)
 
-// Element-wise operator (3D, remo_opts_t.op = 1): everything y = A x needs instead of the stored matrix
-template <class T> struct ElemOpT {
-    int64_t nt = 0;
-    const int32_t *eldof = nullptr;   // [nt][20] free row of every local dof or -1
-    const double *C = nullptr;        // [nt][6] metric terms (launch_metric_terms)
-    const int32_t *adjptr = nullptr;  // [n + 1] row -> incident (element, local dof) codes, ascending
-    const uint32_t *adj = nullptr;    // element << 5 | local dof
-    const int32_t *slot = nullptr;    // [nt][20] position of (element, local dof) in the adjacency list, -1 = constrained (launch_elem_slots)
-    int64_t nadj = 0;                 // upper bound of the adjacency entries (nt * 20): rows of the slab
-    T *Ye = nullptr;                  // [nadj][k] scratch slab: an element's result rows at their adjacency positions
-};
-void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s);
-
 // Patch operator (3D, remo_opts_t.op = 3; patch.hip): the element list cut into runs of E elements, one workgroup each
 struct PatchTables {
     int64_t nt = 0, n = 0, npatch = 0;
@@ -129,7 +116,6 @@ template <class T> struct CsrViewT {
     // rows [pair_begin, pair_end) are the two dofs of each free edge, consecutive and with identical
     // column patterns; their VALUES are stored interleaved (launch_assemble).  0, 0 = no pairs, plain CSR
     int64_t pair_begin = 0, pair_end = 0;
-    const ElemOpT<T> *elem = nullptr;   // != nullptr: launch_spmm applies the element-wise operator instead of the stored entries
     const PatchOpT<T> *patch = nullptr; // != nullptr: launch_spmm applies the patch operator (patch.hip)
     bool vertex_block_only = false;     // rowptr / col / val hold only the leading P1 block (rows and columns < the free vertex count): products need `patch`
 };

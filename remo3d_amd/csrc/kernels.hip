@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(256) k_assemble(int64_t nfree, int64_t pair_be
                         const int32_t mid = (lo + hi) >> 1;
                         if (cl[mid] < j) lo = mid + 1; else hi = mid;
                     }
-                    pos = lo;
+                    // (vertex-block-only assembly: the row holds vertex columns only, every other local dof of the element ends
+                    // behind the row's last column or between two of them - a hit counts only if the column is really there;
+                    // a row of exactly kAsmRow entries would otherwise add into the next wave's accumulators)
+                    pos = (lo < len && cl[lo] == j) ? lo : -1;
                     const double *c = C + t * NT;
                     k = kentry<DIM>(c, M, li, q);
                     if (in_pairs) k2 = kentry<DIM>(c, M, li + 1, q);
@@ -501,149 +504,6 @@ __global__ void __launch_bounds__(512) k_spmm_pair(int64_t n, int64_t pair_begin
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Element-wise operator (3D, remo_opts_t.op = 1): y = A x WITHOUT the assembled matrix.
-//   pass 1 (k_elem_apply): every tetrahedron gathers the 20 rows of x it touches ONCE, forms Y_e = K_e X_e through the
-//     factorised reference tensors (gen_elem_code.cpp: 492 multiply-adds per right-hand side instead of 400 stored entries
-//     times the 20 rows that share them) and writes its 20 result rows to a scratch slab;
-//   pass 2 (k_elem_reduce): every matrix row sums the slab rows of its incident elements (the adjacency list the assembly
-//     gathers through), in ascending element order - deterministic, no atomics - and leaves the <x, y> partial sums.
-// What it buys: the CSR product gathers an x row once per STORED ENTRY (54 times per edge row pair), this one once per
-// incident ELEMENT (6.3 M lane-requests instead of 42 M at 63 k tetrahedra), and it reads 128 bytes per element instead
-// of 2.6 kB of matrix: the work moves from the vector-memory path, which bounds the CSR kernel, to the fp64 pipes.
-#define REMO_ELEM_NS elem_tables_kernels
-#include "build/elem_apply.inc"
-
-// slot[t * 20 + li] = position of (element t, local dof li) in the row-sorted adjacency list, -1 for constrained dofs: where
-// pass 1 puts an element's result rows so that pass 2 finds the contributions of a matrix row side by side
-__global__ void __launch_bounds__(256) k_elem_slots(int64_t n, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj, int32_t *__restrict__ slot) {
-    const int64_t total = adjptr[n];
-    for (int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; a < total; a += int64_t(gridDim.x) * blockDim.x) {
-        const uint32_t code = adj[a];
-        slot[int64_t(code >> 5) * 20 + int64_t(code & 31u)] = int32_t(a);
-    }
-}
-void launch_elem_slots(int64_t n, int64_t nt, const int32_t *adjptr, const uint32_t *adj, int32_t *slot, hipStream_t s) {
-    (void)hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * size_t(nt) * 20, s);
-    hipLaunchKernelGGL(k_elem_slots, dim3(2048), dim3(256), 0, s, n, adjptr, adj, slot);
-}
-
-// Pass 1.  Lane = (tetrahedron, PAIR of right-hand sides): k = 5 takes three lanes per element, 21 elements per wave.  A
-// lane gathers 16 bytes of every x row (the three lanes of an element 16 + 16 + 8: as many requests as one 40-byte row),
-// carries both columns through the factorised tensors as 2-vectors (every constant is materialised once for two
-// multiply-adds, and the two are independent), and stores its two columns of the 20 result rows at the rows' adjacency
-// slots.  ~200 VGPRs: two waves per SIMD.  (One lane per element with all columns in registers - 256 VGPRs + 68 AGPRs,
-// one wave per SIMD - ran 15 cycles per instruction: dependent fp64 chains and SGPR spills with nothing to hide them;
-// one lane per (element, column) needs 2.6x the requests.)
-template <class T, int K>
-__global__ void __launch_bounds__(256) k_elem_apply(int64_t nt, int64_t n, int64_t nadj, const int32_t *__restrict__ eldof, const int32_t *__restrict__ slot,
-                                                    const double *__restrict__ C, const T *__restrict__ x, T *__restrict__ Ye,
-                                                    const double *__restrict__ scal, int step) {
-    if (scal && solve_done(scal, step)) return;
-    typedef T T2 __attribute__((ext_vector_type(2)));
-    constexpr uint32_t S = sizeof(T);
-    constexpr int NL = (K + 1) / 2, EPW = 64 / NL;       // lanes per element, elements per wave
-    const rsrc_t rx = make_rsrc(x, uint64_t(n) * K * S), ry = make_rsrc(Ye, uint64_t(nadj) * K * S);
-    const int lane = threadIdx.x & 63;
-    const int es = lane / NL, c0 = 2 * (lane - es * NL);
-    const bool two = c0 + 1 < K;                          // the last lane of an odd k carries one column
-    if (es >= EPW) return;
-    // Workgroups b, b + 8, ... share an XCD and its L2: every XCD takes ONE contiguous eighth of the elements (elements that are
-    // close in the list are close in the mesh: the x rows they share are served by that L2, and the 40-byte slab rows that
-    // share a 128-byte line are written through the same L2), every workgroup one contiguous chunk of it.
-    const int G = int(gridDim.x);
-    const int vb = (G & 7) == 0 ? int(blockIdx.x & 7) * (G >> 3) + int(blockIdx.x >> 3) : int(blockIdx.x);
-    const int64_t chunk = ((nt + G - 1) / G + 4 * EPW - 1) / (4 * EPW) * (4 * EPW), e_end = (int64_t(vb) + 1) * chunk < nt ? (int64_t(vb) + 1) * chunk : nt;
-    for (int64_t e = int64_t(vb) * chunk + int64_t(threadIdx.x >> 6) * EPW + es; e < e_end; e += int64_t(blockDim.x >> 6) * EPW) {
-        int32_t ed[20], sl[20];
-        {
-            const int4 *pe = reinterpret_cast<const int4 *>(eldof + e * 20), *ps = reinterpret_cast<const int4 *>(slot + e * 20);   // 80-byte records: 16-byte aligned
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int4 a = pe[q], b = ps[q];
-                ed[4 * q] = a.x; ed[4 * q + 1] = a.y; ed[4 * q + 2] = a.z; ed[4 * q + 3] = a.w;
-                sl[4 * q] = b.x; sl[4 * q + 1] = b.y; sl[4 * q + 2] = b.z; sl[4 * q + 3] = b.w;
-            }
-        }
-        const double *ce = C + e * 6;                               // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-        const T c11 = T(ce[0]), c12 = T(ce[1]), c13 = T(ce[2]), c22 = T(ce[3]), c23 = T(ce[4]), c33 = T(ce[5]);
-        T2 xv[20], g[30], y[20];
-#pragma unroll
-        for (int i = 0; i < 20; ++i) {     // constrained dofs carry u = 0; a lone last column reads its right neighbour too (ignored below)
-            T w[2];
-            buf_load<T, 2>(rx, ed[i] >= 0 ? (uint32_t(ed[i]) * K + c0) * S : kOutOfRange, w);
-            xv[i].x = w[0]; xv[i].y = two ? w[1] : T(0);
-        }
-        REMO_ELEM_GRAD_LIT(T2, xv, g)
-#pragma unroll
-        for (int m = 0; m < 10; ++m) {     // h = c~ g, in place
-            const T2 g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
-            g[m] = c11 * g1 + c12 * g2 + c13 * g3;
-            g[10 + m] = c12 * g1 + c22 * g2 + c23 * g3;
-            g[20 + m] = c13 * g1 + c23 * g2 + c33 * g3;
-        }
-        REMO_ELEM_DIV_LIT(T2, g, y)
-#pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const uint32_t off = sl[i] >= 0 ? (uint32_t(sl[i]) * K + c0) * S : kOutOfRange;
-            T w1[1] = {y[i].x}, w2[2] = {y[i].x, y[i].y};
-            buf_store<T, 2>(ry, two ? off : kOutOfRange, w2);       // one store of both columns, or of the lone last column
-            buf_store<T, 1>(ry, two ? kOutOfRange : off, w1);
-        }
-    }
-}
-
-// Pass 2.  One lane per matrix row: the row's contributions are adjacent in the slab (adjacency order = ascending elements:
-// the same fixed summation order as the assembly), read as whole k-wide rows.
-template <class T, int K, bool DOT>
-__global__ void __launch_bounds__(256) k_elem_reduce(int64_t n, int64_t nadj, const int32_t *__restrict__ adjptr, const T *__restrict__ Ye,
-                                                     const T *__restrict__ x, T *__restrict__ y, double *__restrict__ part,
-                                                     const double *__restrict__ scal, int step) {
-    if (scal && solve_done(scal, step)) return;
-    constexpr uint32_t S = sizeof(T);
-    const rsrc_t rs = make_rsrc(Ye, uint64_t(nadj) * K * S), rxx = make_rsrc(x, uint64_t(n) * K * S), ryy = make_rsrc(y, uint64_t(n) * K * S);
-    double dot[K];
-#pragma unroll
-    for (int c = 0; c < K; ++c) dot[c] = 0.0;
-    for (int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += int64_t(gridDim.x) * blockDim.x) {
-        const int32_t as = adjptr[row], ae = adjptr[row + 1];
-        T acc[K];
-#pragma unroll
-        for (int c = 0; c < K; ++c) acc[c] = T(0);
-        for (int32_t a = as; a < ae; a += 4) {          // four slab rows in flight (rows past the end: out of range, zero, no request)
-            T v[4][K];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) buf_load<T, K>(rs, a + u < ae ? uint32_t(a + u) * (K * S) : kOutOfRange, v[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int c = 0; c < K; ++c) acc[c] += v[u][c];
-        }
-        buf_store<T, K>(ryy, uint32_t(row) * (K * S), acc);
-        if (DOT) {
-            T xr[K];
-            buf_load<T, K>(rxx, uint32_t(row) * (K * S), xr);
-#pragma unroll
-            for (int c = 0; c < K; ++c) dot[c] += double(acc[c]) * double(xr[c]);
-        }
-    }
-    if (DOT) {
-        __shared__ double smem[16 * K];
-        block_sum<K>(dot, smem);
-        if (threadIdx.x < K) part[blockIdx.x * K + threadIdx.x] = pick<K>(dot, threadIdx.x);
-    }
-}
-
-template <class T, int K> static void elem_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s) {
-    const ElemOpT<T> &E = *A.elem;
-    constexpr int EPW = 64 / ((K + 1) / 2);
-    int64_t g1 = (E.nt + 4 * EPW - 1) / (4 * EPW);      // one trip of its four waves per workgroup (a capped grid left a ragged second trip: 249 vs 219 us at 443 k elements)
-    g1 = (g1 + 7) / 8 * 8;       // whole residue classes mod 8: one per XCD
-    hipLaunchKernelGGL((k_elem_apply<T, K>), dim3(int(g1)), dim3(256), 0, s, E.nt, A.n, E.nadj, E.eldof, E.slot, E.C, x, E.Ye, scal, step);
-    if (part) hipLaunchKernelGGL((k_elem_reduce<T, K, true>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
-    else hipLaunchKernelGGL((k_elem_reduce<T, K, false>), dim3(nb), dim3(256), 0, s, A.n, E.nadj, E.adjptr, (const T *)E.Ye, x, y, part, scal, step);
-}
-
 // tuning knobs (remo_debug_tune): 0 = heuristic default
 struct SpmmTuning {
     int mode = 0;     // ablation mode of the pair kernel (K = 5, 16 lanes per row only)
@@ -749,19 +609,6 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
     // that (inspection hooks only) goes through the stored matrix
     if (patch_applies(A, k)) {
         launch_patch_spmm(A, k, x, y, part, scal, nb, s, step, defer);
-        return;
-    }
-    if (A.elem) {     // element-wise operator instead of the stored matrix
-        switch (k) {
-            case 1: elem_dispatch<T, 1>(A, x, y, part, scal, step, nb, s); break;
-            case 2: elem_dispatch<T, 2>(A, x, y, part, scal, step, nb, s); break;
-            case 3: elem_dispatch<T, 3>(A, x, y, part, scal, step, nb, s); break;
-            case 4: elem_dispatch<T, 4>(A, x, y, part, scal, step, nb, s); break;
-            case 5: elem_dispatch<T, 5>(A, x, y, part, scal, step, nb, s); break;
-            case 6: elem_dispatch<T, 6>(A, x, y, part, scal, step, nb, s); break;
-            case 7: elem_dispatch<T, 7>(A, x, y, part, scal, step, nb, s); break;
-            default: elem_dispatch<T, 8>(A, x, y, part, scal, step, nb, s); break;
-        }
         return;
     }
     switch (k) {

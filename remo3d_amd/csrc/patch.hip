@@ -552,7 +552,11 @@ void set_patch_spread(int v) { g_patch_spread = v; }
 int g_patch_slab_rows = 0;  // remo_debug_tune key 23: 1 = boundary slab row-major
 void set_patch_slab_rows(int v) { g_patch_slab_rows = v ? 1 : 0; }
 int g_patch_block = 256;   // remo_debug_tune key 19: threads per workgroup of the patch kernel, 256 or 512 (the tables are laid out for it)
+#ifdef REMO_PROBES
 void set_patch_block(int b) { g_patch_block = (b == 512) ? 512 : 256; }
+#else
+void set_patch_block(int) {}
+#endif
 // one lane per (element, right-hand side); at most 204 elements (the table builder sorts 20 slots per element in 32 KB of LDS)
 int patch_elements_per_group(int kmax) { const int e = g_patch_block / (kmax > 0 ? kmax : 1); return e < 204 ? e : 204; }   // 204 x 20 slots sort in 4096 LDS keys
 
@@ -621,6 +625,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
+#ifdef REMO_PROBES      // ablations (wrong results on purpose), the phase probe and 512-thread workgroups: tools/ builds only (make probes)
     if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
         if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
             launched = true;
@@ -637,9 +642,14 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
             }
         }
     }
-    if (!launched) {
-        if (tb.block == 512) launch(k_patch_apply<T, K, 512, 0>, 512);
-        else if (g_patch_lean == 1 || (g_patch_lean < 0 && sizeof(T) == 4)) launch(k_patch_apply<T, K, 256, 0, true>, 256);
+    if (!launched && tb.block == 512) { launch(k_patch_apply<T, K, 512, 0>, 512); launched = true; }
+    if (!launched && ((g_patch_lean == 1) != (sizeof(T) == 4)) && g_patch_lean >= 0) {     // the other order than the product's
+        if (sizeof(T) == 4) launch(k_patch_apply<T, K, 256, 0>, 256); else launch(k_patch_apply<T, K, 256, 0, true>, 256);
+        launched = true;
+    }
+#endif
+    if (!launched) {     // the product: plain order in fp64 (124 registers, four waves per SIMD), register-lean order in fp32 storage (seven)
+        if constexpr (sizeof(T) == 4) launch(k_patch_apply<T, K, 256, 0, true>, 256);
         else launch(k_patch_apply<T, K, 256, 0>, 256);
     }
     if (bins) return;     // the patches have added their sums into the update launch's rows themselves

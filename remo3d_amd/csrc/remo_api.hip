@@ -110,8 +110,6 @@ struct remo_batch {
     double *d_val = nullptr, *d_dinv = nullptr;
     double *d_x = nullptr, *d_C = nullptr;  // solution block [n][k_last] and metric terms of the last run
     double *d_f = nullptr;                  // load vectors [n][k_last] of the last chunk
-    ElemOpT<double> elem64{};               // element-wise operator of the last run (remo_opts_t.op = 1), pointers into the arena
-    ElemOpT<float> elem32{};
     PatchOpT<double> patch64{};             // patch operator of the last run (remo_opts_t.op = 3), pointers into the arena
     PatchOpT<float> patch32{};
     AmgT<double> amg64{};                   // multigrid hierarchy of the vertex block of the last run (arena)
@@ -146,13 +144,10 @@ int g_sq_lanes = 0;  // key 7: lanes per row of the paired kernel (0 = by row le
 int g_amg32 = 1;     // key 17: 1 = fp64 solves run the multigrid cycle in fp32 storage (default), 0 = in fp64
 int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the multigrid cycle, 2 = always (any dimension)
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
-inline bool g_auto_patch_ok(int op);
 int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
 int g_dot_bins = 1;   // key 28: 1 = the patches add their <p, A p> straight into the update launch's rows (default), 0 = a row per patch + k_patch_dot
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
-int g_auto_patch = 1; // key 20: 1 = op 0 takes the patch operator in 3D whenever its tables fit (default), 0 = the round-2 choice by size
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
-inline bool g_auto_patch_ok(int op) { return op == 3 || g_auto_patch != 0; }
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
 // fp64 side of a mixed-precision inner solve: where the residual replacements read and write
@@ -488,6 +483,8 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
     remo_opts_t o;
     if (opts_in) o = *opts_in; else remo_opts_default(&o);
     if (o.maxsteps <= 0 || !(o.rtol > 0.0)) return fail(ctx, REMO_ERR_ARG, "maxsteps and rtol must be positive");
+    if (o.op != 0 && o.op != 2 && o.op != 3)
+        return fail(ctx, REMO_ERR_ARG, "remo_opts_t.op must be 0 (default), 2 (CSR product) or 3 (patch operator); 1, the round-2 element-wise operator, left the library with ABI 7");
     remo_stats_t local;
     if (!st) st = &local;
     std::memset(st, 0, sizeof *st);
@@ -528,11 +525,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         const int64_t ndof_max = nv + (dim == 2 ? 7 : 16) * nt, nnz_max = nt * int64_t(N) * N;
         size_t need = symbolic_gpu_arena_bytes(dim, nv, nt, b->nbf);
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
-        // element result slab(s) of the round-2 element-wise operator: only when it is asked for, or (patch operator switched off
-        // by the probe knob) may be chosen by size - a run that ends on the patch operator or the CSR product never pays for it
-        const bool reserve_elem = dim == 3 && (o.op == 1 || (o.op == 0 && !g_auto_patch && nnz_max / 8 > 17000000));
-        if (reserve_elem)
-            need += size_t(nt) * 20 * (size_t(kmax) * (o.precision == 1 ? 12 : 8) + 4) + 8192;
+        // the patch operator is 3D only; a 2D batch always runs on the CSR product, whatever `op` says
         const bool want_patch = dim == 3 && (o.op == 3 || o.op == 0);
         if (want_patch) need += patch_arena_bytes(nt, ndof_max, kmax) + size_t(nt) * 20 * size_t(kmax) * 8;   // tables + boundary slab (upper bound)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
@@ -552,7 +545,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         std::string err;
         DeviceSymbolic &sy = b->sym;
         // patch operator batches above 200 k tetrahedra (assemble = 2: any size) number only the P1 block of the matrix
-        const bool want_patch0 = dim == 3 && (o.op == 3 || o.op == 0) && g_auto_patch_ok(o.op);
+        const bool want_patch0 = want_patch;
         const int64_t vertex_block_above = (want_patch0 && o.assemble != 1) ? (o.assemble == 2 ? 0 : 200000) : -1;
         int rc = build_symbolic_gpu(ctx->ar, s, dim, nv, nt, b->d_conn, b->nbf, b->d_bconn, b->d_bdir, o.condense != 0, ctx->d_err, sy, err, vertex_block_above);
         if (rc != REMO_OK) return fail(ctx, rc, err);
@@ -753,29 +746,22 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->A = CsrView{n, sy.nnz, sy.rowptr, sy.col, d_val};
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
         b->A.vertex_block_only = lite;
-        // measured (bench, fp64, k = 5): 13.7 M stored entries CSR 49 us / element-wise 61; 21.6 M 102 / 78; 32.8 M 148 / 109; 93 M 472 / 381
-        // (its buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
-        const bool elem_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
+        // (the patch kernel's buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
+        const bool slab_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
-        // (an element list without locality) sends op = 0 on to the older choices and fails op = 3
+        // (an element list without locality) sends op = 0 on to the CSR product and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
         const size_t patch_lds = ptab.block > 0 ? patch_lds_bytes(h_patch[1], kmax, ptab.block) : 0;   // what k_patch_apply asks for (kernels.hip patch_applies)
-        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && elem_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= kPatchLdsLimit;
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && slab_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= kPatchLdsLimit;
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
-        if (o.op == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is 2D / too large)");
-        const bool patch_op = patch_ok && (lite || o.op == 3 || (o.op == 0 && g_auto_patch));
-        const bool elem_op = !patch_op && dim == 3 && elem_fits && reserve_elem && (o.op == 1 || (o.op == 0 && sy.nnz > 17000000));   // (else: the CSR product)
-        st->op_used = patch_op ? 3 : (elem_op ? 1 : 0);
+        if (o.op == 3 && dim == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is too large)");
+        const bool patch_op = patch_ok;
+        st->op_used = patch_op ? 3 : 0;
+        st->assembled = lite ? 2 : 1;
         if (patch_op) {
             ptab.nslot_cap = h_patch[2] > 0 ? h_patch[2] : 1;     // the slab holds the slots in use
             b->patch64 = PatchOpT<double>{ptab, ctx->take<double>(size_t(ptab.nslot_cap) * size_t(kmax) + 8), ctx->take<double>(size_t(ptab.npatch) * 8 + 8), h_patch[1]};
             b->A.patch = &b->patch64;
-        }
-        if (elem_op) {   // the CG applies A element by element (kernels.hip k_elem_apply / k_elem_reduce)
-            int32_t *d_slot = ctx->take<int32_t>(size_t(nt) * 20 + 4);
-            launch_elem_slots(n, nt, sy.adjptr, sy.adj, d_slot, s);
-            b->elem64 = ElemOpT<double>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, d_slot, nt * 20, ctx->take<double>(size_t(nt) * 20 * size_t(kmax))};
-            b->A.elem = &b->elem64;
         }
         b->d_val = d_val;
         b->d_dinv = d_dinv;
@@ -807,10 +793,6 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             if (patch_op) {   // the slab and the partial sums are scratch of one application: the fp32 operator shares them
                 b->patch32 = PatchOpT<float>{ptab, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, h_patch[1]};
                 mx.A32.patch = &b->patch32;
-            }
-            if (elem_op) {
-                b->elem32 = ElemOpT<float>{nt, sy.eldof, d_C, sy.adjptr, sy.adj, b->elem64.slot, nt * 20, ctx->take<float>(size_t(nt) * 20 * size_t(kmax))};
-                mx.A32.elem = &b->elem32;
             }
             PcgBuffersT<float> &f = mx.b32;
             f.x = ctx->take<float>(size_t(n) * kmax); f.r = ctx->take<float>(size_t(n) * kmax);
@@ -1314,6 +1296,10 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
 
 int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, double *out16) {
     if (!ctx || !b || !out16) return REMO_ERR_ARG;
+#ifndef REMO_PROBES
+    (void)fp32;
+    return fail(ctx, REMO_ERR_ARG, "remo_debug_patch_phases: the library was built without -DREMO_PROBES (make -C remo3d_amd/csrc probes)");
+#else
     if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");
     const int k = 5;
     if (k * b->patch64.t.E > b->patch64.t.block) return fail(ctx, REMO_ERR_ARG, "the batch's patch tables are laid out for fewer than 5 columns");
@@ -1386,30 +1372,43 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, doub
         if (st) (void)hipFree(st);
         return fail(ctx, REMO_ERR_DEVICE, ex.what());
     }
+#endif
 }
 
-void remo_debug_tune(int32_t key, int32_t value) {
-    if (key == 6) g_square = value;
-    else if (key == 7) g_sq_lanes = value;
+int remo_debug_tune(int32_t key, int32_t value) {
+    // Keys that force ONE OF THE PRODUCT'S OWN PATHS - a choice the library makes by size or dimension, forced so that a small test
+    // mesh reaches the code a large batch runs; every setting gives the same operator / preconditioner to rounding: always there.
+    switch (key) {
+        case 3: set_spmm_tuning(3, value); return 0;    // row schedule of the CSR product
+        case 6: g_square = value; return 0;             // paired Chebyshev steps
+        case 9: set_fold_first(value); return 0;        // first Chebyshev step inside the update launch
+        case 13: g_compact = value; return 0;           // compact copy of the vertex block
+        case 15: g_chain32 = value; return 0;           // fp32 Chebyshev chain inside fp64 solves
+        case 16: g_amg = value; return 0;               // multigrid cycle on the vertex block
+        case 17: g_amg32 = value; return 0;             // ... in fp32 storage
+        case 18: set_element_order(value); return 0;    // elements in the caller's order
+        case 22: g_defer_q = value; return 0;           // shared rows summed by k_patch_reduce / by the update launch
+        case 24: g_ell = value; return 0;               // fixed-width image of the vertex block
+        default: break;
+    }
+#ifdef REMO_PROBES
+    // Keys of rejected experiments and ablations (some give wrong results on purpose): tools/ builds only (make probes)
+    if (key == 7) g_sq_lanes = value;
     else if (key == 8) set_symbolic_tuning(value);
-    else if (key == 18) set_element_order(value);
     else if (key == 19) set_patch_block(value);
-    else if (key == 20) g_auto_patch = value;
     else if (key == 21) set_patch_mode(value);
-    else if (key == 22) g_defer_q = value;
     else if (key == 23) set_patch_slab_rows(value);
-    else if (key == 24) g_ell = value;
     else if (key == 26) set_patch_lean(value);
     else if (key == 27) set_slab_ahead(value);
     else if (key == 28) g_dot_bins = value;
     else if (key == 32) set_patch_spread(value);
     else if (key == 33) set_patch_trim(value);
-    else if (key == 9) set_fold_first(value);
-    else if (key == 13) g_compact = value;
-    else if (key == 15) g_chain32 = value;
-    else if (key == 16) g_amg = value;
-    else if (key == 17) g_amg32 = value;
     else set_spmm_tuning(key, value);
+    return 0;
+#else
+    (void)value;
+    return -1;      // not in this build
+#endif
 }
 
 int remo_host_element_matrix(int32_t dim, const double *X, double sigma, double *K_out) {

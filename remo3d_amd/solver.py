@@ -15,6 +15,7 @@ from ._lib import RemoOpts, RemoStats, ptr
 
 REMO_OK = 0
 REMO_NOT_CONVERGED = 1
+REMO_ERR_ARG = -1
 
 
 class RemoError(RuntimeError):
@@ -47,9 +48,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     o.precision = 1 if precision == "mixed" else 0
     o.inner_digits = int(inner_digits)
     o.serialize_solves = 1 if serialize_solves else 0   # several contexts: one PCG at a time, the others prepare (see the header)
-    if op not in ("auto", "csr", "element", "patch"):
-        raise ValueError("op must be 'auto' (by size), 'csr' (SpMM on the assembled matrix) or 'element' (element-wise operator, 3D)")
-    o.op = {"auto": 0, "element": 1, "csr": 2, "patch": 3}[op]
+    if op not in ("auto", "csr", "patch"):
+        raise ValueError("op must be 'auto' (patch operator in 3D, CSR product in 2D), 'csr' (SpMM on the assembled matrix) or 'patch' (matrix-free, 3D)")
+    o.op = {"auto": 0, "csr": 2, "patch": 3}[op]
     if coarse not in ("auto", "chebyshev", "amg"):
         raise ValueError("coarse must be 'auto' (multigrid cycle in 2D, Chebyshev polynomial in 3D), 'chebyshev' or 'amg'")
     o.coarse = {"auto": 0, "chebyshev": 1, "amg": 2}[coarse]   # solver of the P1 block inside "multigrid"

@@ -43,33 +43,50 @@ def my_share(n_batches: int, r: Optional[int] = None, w: Optional[int] = None) -
 
 
 _STORE = None          # the TCPStore the sweep owns (dynamic schedule); created once per process group, collectively
+_STORE_GROUP = None    # the process group it was made for
 _SWEEP_SEQ = 0         # rank 0's count of dynamic queues: the id it broadcasts names the shared counter
 
 
 def _own_store():
     """A TCPStore of the sweep's own for the shared batch counter: rank 0 hosts it on a free local port and tells the
     others through one broadcast (collective: every rank of the group must get here).  The process group's private
-    rendezvous store is not touched."""
-    global _STORE
-    if _STORE is not None:
-        return _STORE
+    rendezvous store is not touched.  Rank 0 tries a few ports (another process can take a probed port before the store binds
+    it) and broadcasts a (port | error) record, so that a failure raises on EVERY rank instead of leaving the others in the
+    broadcast; the store is kept per process group (a new group makes a new store)."""
+    global _STORE, _STORE_GROUP
     import datetime
     import socket
     import torch.distributed as dist
+    group = dist.distributed_c10d._get_default_group() if hasattr(dist, "distributed_c10d") else None
+    if _STORE is not None and _STORE_GROUP is group:
+        return _STORE
+    _STORE = None
     host = os.environ.get("REMO_STORE_ADDR", os.environ.get("MASTER_ADDR", "127.0.0.1"))
     box = [None]
     if dist.get_rank() == 0:
-        s = socket.socket()
-        s.bind(("", 0))
-        port = s.getsockname()[1]
-        s.close()
-        _STORE = dist.TCPStore(host, port, world_size=dist.get_world_size(), is_master=True, wait_for_workers=False,
-                               timeout=datetime.timedelta(seconds=300))
-        box[0] = port
+        err = None
+        for _ in range(8):
+            s = socket.socket()
+            s.bind(("", 0))
+            port = s.getsockname()[1]
+            s.close()
+            try:
+                _STORE = dist.TCPStore(host, port, world_size=dist.get_world_size(), is_master=True, wait_for_workers=False,
+                                       timeout=datetime.timedelta(seconds=300))
+                box[0] = ("port", port)
+                break
+            except Exception as ex:      # the port went to somebody else in between (or MASTER_ADDR is not this host): next port
+                err = "%s: %s" % (type(ex).__name__, ex)
+        if box[0] is None:
+            box[0] = ("error", "rank 0 could not host the sweep's TCPStore on %s: %s" % (host, err))
     dist.broadcast_object_list(box, src=0)
+    kind, payload = box[0]
+    if kind == "error":
+        raise RuntimeError(payload)
     if dist.get_rank() != 0:
-        _STORE = dist.TCPStore(host, int(box[0]), world_size=dist.get_world_size(), is_master=False,
+        _STORE = dist.TCPStore(host, int(payload), world_size=dist.get_world_size(), is_master=False,
                                timeout=datetime.timedelta(seconds=300))
+    _STORE_GROUP = group
     return _STORE
 
 

@@ -46,7 +46,7 @@ def main():
     form = np.array([[0.0, 30.0, np.nan, np.nan, 7.0], [30.0, 60.0, np.nan, np.nan, 7.0]])
     bore = np.array([[0.0, 0.2, 7.0], [60.0, 0.2, 7.0]])
     m.set_model_parameters(form, bore)
-    m.initialize_workers(cpu_workers=1, gpu_workers=0, context_factory=lambda device: FakeContext())
+    m.initialize_workers(cpu_workers=1, gpu_workers=1, context_factory=lambda device: FakeContext())     # one context per rank (0 = the default of two)
     depths = np.arange(10.0, 20.0, 0.25) if mode != "one_batch" else np.array([12.0])
     fail_index = 3 if mode != "one_batch" else -1
 

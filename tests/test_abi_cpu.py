@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert set(_lib.EXPORTS) == declared
     assert set(_lib.DEBUG_EXPORTS) == debug
-    assert L.remo_abi_version() == 6
+    assert L.remo_abi_version() == 7
 
 
 def test_options_defaults_follow_reference():

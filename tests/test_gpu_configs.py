@@ -4,7 +4,8 @@
     solves the test meshes with NGSolve and the HIP path must agree to 1e-6 on apparent resistivity (north star).
   * the reference's complete committed logs: Example_01, Example_02, thin-bedded Logs 1-4 (every point, asserted percentiles);
   * config 2: Benchmark model 1 (2D), one normal tool, 100 depths: HIP vs the CPU oracle on every right-hand side;
-  * config 5: one batch of the ~5 M-dof mesh, mixed precision vs fp64, properties, TRUE residual;
+  * config 3: two batches of the headline sweep at size L (normal + lateral tool, ten right-hand sides) on the library's default path vs the oracle;
+  * config 5: one batch of the ~5 M-dof mesh on the default (patch) operator and on the assembled matrix, mixed precision vs fp64, properties, TRUE residual;
   * dipping 3D: closed-form image solution across a plane interface inclined by 30 degrees;
   * MSH 2.2 files into the HIP path;
   * many short solves on two contexts at once (the "all columns frozen" flag must not split a workgroup).
@@ -273,10 +274,45 @@ def test_config1_bm1_hip_against_the_oracle(examples_dir, gpu_ctx):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_config3_size_L_batches_against_the_oracle(precision, gpu_ctx, size_L_case):
+    """BASELINE configs[2] at its own workload and size (bench.py's headline): Benchmark model 3, dip 30, tools A0.4M6.0N
+    (normal) + A2.0M0.5N (lateral), 100 depths, batch 5, meshes at size L - two of its 40 batches (batch 0: lateral tool; batch 20:
+    both tools; ten right-hand sides, 1.5-1.7 M unknowns each) through the calls `Model.simulate_logs` makes per batch
+    (Context.solve_batch with the library's defaults: patch operator, P1 block + diagonal assembled, Chebyshev vertex solver;
+    tasks.apparent_resistivity) and through the CPU oracle, right-hand side by right-hand side (threads started by the fixture):
+    potentials within 2e-8 (fp64) / 1e-6 (mixed), apparent resistivity within 1e-6 (the north star's tolerance)."""
+    from remo3d_amd import solver, tasks
+    worst_u = worst_ra = 0.0
+    n_rhs = 0
+    for bi, w in enumerate(size_L_case["work"]):
+        outs, st, rc = gpu_ctx.solve_batch(w["mesh"], w["sigma"], w["sources"], w["evals"], solver.make_opts(rtol=1e-10, precision=precision))
+        assert rc == 0, st
+        assert st["op_used"] == 3 and st["nnz"] == 0 and st["coarse_used"] == 1 and st["n_free"] > 1400000, st
+        for k, (u, rd) in enumerate(zip(outs, w["readers"])):
+            ref, rc_o, st_o = size_L_case["futs"][(bi, k)].result(timeout=1200)
+            assert rc_o == 0 and st_o["n"] == st["n_free"]
+            worst_u = max(worst_u, float(np.max(np.abs(u - ref) / np.abs(ref))))
+            for (di, ti, K, o, mm) in rd:
+                a, c = tasks.apparent_resistivity(u[o:o + mm], mm, K, 3), tasks.apparent_resistivity(np.asarray(ref)[o:o + mm], mm, K, 3)
+                worst_ra = max(worst_ra, abs(a - c) / abs(c))
+            n_rhs += 1
+    assert n_rhs == 10
+    tools_seen = sorted({ti for w in size_L_case["work"] for rd in w["readers"] for (di, ti, K, o, mm) in rd})
+    assert tools_seen == [0, 1]                          # normal and lateral tool
+    _record("config3_sizeL_parity_%s.json" % precision, dict(batches=2, rhs=n_rhs, mesh_T=[int(w["mesh"].n_elems) for w in size_L_case["work"]],
+                                                             max_rel_diff_potential=worst_u, max_rel_diff_ra=worst_ra, rtol=1e-10, precision=precision))
+    print("config 3 at size L (%s): potentials %.2e, Ra %.2e" % (precision, worst_u, worst_ra))
+    assert worst_u <= (2e-8 if precision == "fp64" else 1e-6) and worst_ra <= 1e-6, (worst_u, worst_ra)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def test_config5_xl_batch_mixed_precision(gpu_ctx):
     """BASELINE configs[4]: one batch of the ~5 M-dof mesh (bench size XL), fp32 PCG inside fp64 residual refinement against the
-    fp64 solve: potentials within 1e-6, reciprocity, linearity, and the TRUE residual f - A x of both solutions (recomputed from
-    the solution with one device SpMM) at the requested tolerance."""
+    fp64 solve, each on the operator the library picks at this size (op = "auto": the patch operator, nothing of A assembled but
+    the diagonal and the P1 block) and on the assembled matrix (op = "csr", 258 M stored entries): potentials within 1e-6,
+    reciprocity, linearity, and the TRUE residual f - A x of every solution (recomputed from the solution with one device product)
+    at the requested tolerance."""
     import bench
     from remo3d_amd import solver
     w = bench.build_workload(0, 1, 5, bench.SIZES["XL"], max_batches=1)["work"][0]
@@ -287,29 +323,30 @@ def test_config5_xl_batch_mixed_precision(gpu_ctx):
     b = gpu_ctx.batch(mesh, sigma, src, ev)
     res = {}
     try:
-        for precision in ("fp64", "fp64+element", "mixed", "mixed+element"):      # "+element" is what op = "auto" picks at this size
+        for variant in ("fp64", "mixed", "fp64+csr", "mixed+csr"):
             t0 = time.time()
-            rc = b.run(solver.make_opts(rtol=1e-9, precision=precision.split("+")[0], maxsteps=3000, op="element" if "element" in precision else "csr"))
-            assert b.stats["op_used"] == (1 if "element" in precision else 0)
-            assert rc == 0, b.stats
+            csr = variant.endswith("+csr")
+            rc = b.run(solver.make_opts(rtol=1e-9, precision=variant.split("+")[0], maxsteps=3000, op="csr" if csr else "auto"))
             st = b.stats
+            assert rc == 0, st
+            assert st["op_used"] == (0 if csr else 3) and (st["nnz"] > 200000000 if csr else st["nnz"] == 0), st
             assert st["n_free"] > 4500000, st["n_free"]
-            res[precision] = dict(out=[o.copy() for o in b.fetch()], steps=int(st["pcg_steps"]), ms=float(st["ms_solve"]), true_relres=b.true_relres().tolist(),
-                                  wall=time.time() - t0, cycles=int(st["refinement_cycles"]))
+            res[variant] = dict(out=[o.copy() for o in b.fetch()], steps=int(st["pcg_steps"]), ms=float(st["ms_solve"]), true_relres=b.true_relres().tolist(),
+                                wall=time.time() - t0, cycles=int(st["refinement_cycles"]), nnz=int(st["nnz"]))
     finally:
         b.close()
     tol = 1e-6
-    for precision, r in res.items():
+    for variant, r in res.items():
         out = r["out"]
-        assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0]), precision                      # reciprocity u_a(z_b) = u_b(z_a)
-        assert abs(out[2][0] - (out[0][1] - out[1][1])) <= tol * abs(out[0][1]), precision        # dipole = difference of its poles
-        assert np.allclose(out[3], 2.5 * out[0], rtol=tol, atol=0), precision
-        assert max(r["true_relres"]) <= 5e-9, (precision, r["true_relres"])                       # asked for 1e-9 (recurrence / refinement)
-    for other in ("fp64+element", "mixed", "mixed+element"):
+        assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0]), variant                      # reciprocity u_a(z_b) = u_b(z_a)
+        assert abs(out[2][0] - (out[0][1] - out[1][1])) <= tol * abs(out[0][1]), variant        # dipole = difference of its poles
+        assert np.allclose(out[3], 2.5 * out[0], rtol=tol, atol=0), variant
+        assert max(r["true_relres"]) <= 5e-9, (variant, r["true_relres"])                       # asked for 1e-9 (recurrence / refinement)
+    for other in ("mixed", "fp64+csr", "mixed+csr"):
         for a, c in zip(res["fp64"]["out"], res[other]["out"]):
-            assert np.allclose(a, c, rtol=tol, atol=0)
+            assert np.allclose(a, c, rtol=tol, atol=0), other
         assert res[other]["cycles"] >= (1 if "mixed" in other else 0)
-    _record("config5_xl_batch.json", dict(n_free=int(st["n_free"]), nnz=int(st["nnz"]), T=int(mesh.n_elems),
+    _record("config5_xl_batch.json", dict(n_free=int(st["n_free"]), T=int(mesh.n_elems),
                                          **{p: {k: v for k, v in r.items() if k != "out"} for p, r in res.items()},
                                          max_rel_diff_mixed_vs_fp64=float(max(np.max(np.abs(a - c) / np.abs(a)) for a, c in zip(res["fp64"]["out"], res["mixed"]["out"])))))
 

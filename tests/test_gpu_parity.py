@@ -89,8 +89,6 @@ def test_spmv_row_schedules_agree(k, mesh3d, gpu_ctx):
         u_default = b.fetch()[0].copy()
         x = np.random.default_rng(k).standard_normal((o.nfree, k))
         xx = x if k > 1 else x[:, 0]
-        L.remo_debug_tune(0, 3)                                  # the pair kernel, whatever the heuristics say
-        L.remo_debug_tune(1, 16)
         ref = None
         for mapping in (1, 0, 16, 64, 16 * 37, 16 * 512):
             L.remo_debug_tune(3, mapping)
@@ -104,8 +102,7 @@ def test_spmv_row_schedules_agree(k, mesh3d, gpu_ctx):
         b.run(solver.make_opts(rtol=1e-9, op="csr"))
         assert np.max(np.abs(b.fetch()[0] - u_default)) <= 1e-9 * np.max(np.abs(u_default))
     finally:
-        for key, v in ((0, 0), (1, 0), (3, -1)):
-            L.remo_debug_tune(key, v)
+        L.remo_debug_tune(3, -1)
         b.close()
 
 
@@ -358,29 +355,17 @@ def test_ragged_and_degenerate_right_hand_sides(precision, mesh2d, gpu_ctx):
     assert np.allclose(outs[3], [ref[0][2], ref[0][0]], rtol=1e-8, atol=0) and np.isfinite(outs[3][0]) and outs[3][0] > outs[3][1]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp64", "mixed"])
-def test_full_size_batch_properties(precision, gpu_ctx):
-    """The headline workload at its full size (bench.py size S: BM3, dip 30 degrees, ~63 k tetrahedra, ~290 k unknowns, 14 M
-    stored entries) through properties that need no second solver: reciprocity u_a(z_b) = u_b(z_a) of the symmetric operator,
-    linearity in the source strengths (dipole = difference of its poles), scaling of all conductivities by c (u -> u / c),
-    and the two-level and the Jacobi preconditioner agreeing on the solution.  The oracle checks one right-hand side
-    of the same batch (a few seconds on one core)."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+def _batch_properties(gpu_ctx, mesh, sigma, precision, tol=2e-8):
+    """Properties of a batch that need no second solver: reciprocity u_a(z_b) = u_b(z_a) of the symmetric operator, linearity in the
+    source strengths (dipole = difference of its poles), scaling of all conductivities by c (u -> u / c), and the two-level and the
+    Jacobi preconditioner agreeing on the solution.  Returns (potentials of the first right-hand side, stats)."""
     from remo3d_amd import solver
-    from oracle.fem_oracle import solve_batch as oracle_batch
-    w = bench.build_workload(0, 1, 5, bench.SIZES["S"])["work"][0]
-    mesh, sigma = w["mesh"], np.asarray(w["sigma"], dtype=np.float64)
     za, zb, zc = 0.0, 0.4, 6.4
     src = [([za], [1.0]), ([zb], [1.0]), ([za, zb], [1.0, -1.0]), ([za], [2.5])]
     ev = [[zb, zc], [za, zc], [zc, 2.0], [zb, zc]]
     opts = solver.make_opts(rtol=1e-11, precision=precision, maxsteps=3000)
     out, st, rc = gpu_ctx.solve_batch(mesh, sigma, src, ev, opts)
-    assert rc == 0 and st["n_free"] > 250000 and st["nnz"] > 12000000, st
-    tol = 2e-8
+    assert rc == 0, st
     assert abs(out[0][0] - out[1][0]) <= tol * abs(out[0][0])                               # reciprocity
     assert abs(out[2][0] - (out[0][1] - out[1][1])) <= tol * abs(out[0][1])                 # linearity: dipole at z_c
     assert np.allclose(out[3], 2.5 * out[0], rtol=tol, atol=0)                              # strength scaling
@@ -388,9 +373,44 @@ def test_full_size_batch_properties(precision, gpu_ctx):
     assert rc == 0 and np.allclose(out_c[0], out[0] / 4.0, rtol=tol, atol=0)                # conductivity scaling
     out_j, st_j, rc = gpu_ctx.solve_batch(mesh, sigma, src[:1], ev[:1], solver.make_opts(preconditioner="local", rtol=1e-11, precision=precision, maxsteps=5000))
     assert rc == 0 and np.allclose(out_j[0], out[0], rtol=tol, atol=0)
-    ref, rc_o, st_o = oracle_batch(mesh, sigma, [0, 1], [za], [1.0], [0, 2], [zb, zc], condense=True, rtol=1e-11, maxit=5000)
+    return out[0], st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_full_size_batch_properties(precision, gpu_ctx):
+    """A batch of the round-1/2 headline size (bench.py size S: BM3, dip 30 degrees, ~70 k tetrahedra, ~320 k unknowns, 15 M stored
+    entries - below 200 k tetrahedra the whole matrix is assembled beside the patch operator) through its properties, and one
+    right-hand side of the same batch against the oracle (a few seconds on one core)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle.fem_oracle import solve_batch as oracle_batch
+    w = bench.build_workload(0, 1, 5, bench.SIZES["S"])["work"][0]
+    mesh, sigma = w["mesh"], np.asarray(w["sigma"], dtype=np.float64)
+    u0, st = _batch_properties(gpu_ctx, mesh, sigma, precision)
+    assert st["n_free"] > 250000 and st["nnz"] > 12000000 and st["op_used"] == 3, st
+    ref, rc_o, st_o = oracle_batch(mesh, sigma, [0, 1], [0.0], [1.0], [0, 2], [0.4, 6.4], condense=True, rtol=1e-11, maxit=5000)
     assert rc_o == 0 and st_o["n"] == st["n_free"] and st_o["nnz"] == st["nnz"]
-    assert np.allclose(out[0], ref, rtol=tol, atol=0), (out[0], ref)
+    assert np.allclose(u0, ref, rtol=2e-8, atol=0), (u0, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "mixed"])
+def test_headline_size_batch_on_the_default_path(precision, gpu_ctx, size_L_case):
+    """The HEADLINE workload at its own size (bench.py default, size L: batch 0 of the 100-depth sweep, ~370 k tetrahedra, ~1.7 M
+    unknowns) on the path the library picks there by itself: patch operator (op_used 3), only the Jacobi diagonal and the P1
+    block assembled (nnz 0: `assemble` by size), Chebyshev polynomial on the vertex block - the same properties as at size S, and
+    one right-hand side against the oracle (started in a thread by the fixture: ~1 minute of one core)."""
+    w = size_L_case["work"][0]
+    mesh, sigma = w["mesh"], np.asarray(w["sigma"], dtype=np.float64)
+    u0, st = _batch_properties(gpu_ctx, mesh, sigma, precision)
+    assert mesh.n_elems > 300000 and st["n_free"] > 1400000, (mesh.n_elems, st["n_free"])
+    assert st["op_used"] == 3 and st["nnz"] == 0 and st["coarse_used"] == 1, st
+    ref, rc_o, st_o = size_L_case["futs"]["properties"].result(timeout=900)
+    assert rc_o == 0 and st_o["n"] == st["n_free"]
+    assert np.allclose(u0, ref, rtol=2e-8, atol=0), (u0, ref)
 
 
 @pytest.mark.gpu
@@ -541,65 +561,20 @@ def test_patch_operator_on_a_hub_mesh(nrhs, gpu_ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [1, 5, 8])
-def test_element_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
-    """remo_opts_t.op = 1 (3D): y = A x element by element through the factorised reference tensors equals the CSR product and
-    the oracle's (different arithmetic routes: quadrature / contracted tensors / factorised tensors; Dirichlet rows eliminated
-    the same way)."""
-    from remo3d_amd import _lib, solver
-    from oracle.fem_oracle import Oracle
-    assert _lib.load().remo_host_factor_error() < 1e-14
-    o = Oracle(mesh3d, SIGMA3, condense=True)
-    x = np.random.default_rng(k).standard_normal((o.nfree, k))
-    xx = x if k > 1 else x[:, 0]
-    b = gpu_ctx.batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1])
-    try:
-        ys = {}
-        for op in ("csr", "element"):
-            b.run(solver.make_opts(preconditioner="local", rtol=1e-2, op=op))
-            ys[op], _ = b.spmv(xx, reps=2)
-        yr = np.stack([o.spmv(x[:, c]) for c in range(k)], 1).reshape(ys["csr"].shape)
-        scale = np.max(np.abs(yr))
-        assert np.max(np.abs(ys["element"] - yr)) <= 5e-12 * scale
-        assert np.max(np.abs(ys["element"] - ys["csr"])) <= 5e-12 * scale
-    finally:
-        b.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp64", "mixed"])
-@pytest.mark.parametrize("pre", ["local", "multigrid"])
-def test_element_operator_solves_like_the_csr_path(precision, pre, mesh3d, gpu_ctx):
-    """The same PCG on the element-wise operator: potentials of the CSR path and of the oracle, similar step counts, 9 right-hand
-    sides (chunks of 8 + 1); 2D batches ignore the option."""
+def test_operator_option_in_2d_and_removed_values(mesh2d, gpu_ctx):
+    """A 2D batch runs on the CSR product whatever `op` says (the patch operator is 3D only: op = "patch" used to turn every 2D
+    batch of a sweep into NaN); op = 1, the round-2 element-wise operator, left the library with ABI 7 and is an argument error."""
     from remo3d_amd import solver
-    o, ref = _oracle_solve(mesh3d, SIGMA3, True)
-    res = {}
-    for op in ("csr", "element"):
-        outs, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner=pre, rtol=1e-12, maxsteps=20000, precision=precision, op=op))
-        assert rc == 0
-        res[op] = (outs, max(st["iterations"][:3]))
-        for g, r in zip(outs, ref):
-            assert np.max(np.abs(g - r)) <= 1e-8 * np.max(np.abs(r))
-    assert abs(res["csr"][1] - res["element"][1]) <= max(3, res["csr"][1] // 20), (res["csr"][1], res["element"][1])
-    zs = np.linspace(-0.4, 0.4, 9)
-    src = [([z], [1.0]) for z in zs]
-    ev = [[z + 0.4, z + 6.4] for z in zs]
-    a, _, rca = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="element", maxsteps=5000))
-    c, _, rcc = gpu_ctx.solve_batch(mesh3d, SIGMA3, src, ev, solver.make_opts(preconditioner=pre, rtol=1e-11, precision=precision, op="csr", maxsteps=5000))
-    assert rca == 0 and rcc == 0
-    for u, v in zip(a, c):
-        assert np.allclose(u, v, rtol=1e-8, atol=0)
-
-
-@pytest.mark.gpu
-def test_element_operator_is_ignored_in_2d(mesh2d, gpu_ctx):
-    from remo3d_amd import solver
-    a, _, rca = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="element"))
-    c, _, rcc = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="csr"))
-    assert rca == 0 and rcc == 0
+    a, sa, rca = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="patch"))
+    c, sc, rcc = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, op="csr"))
+    assert rca == 0 and rcc == 0 and sa["op_used"] == 0 and sc["op_used"] == 0 and sa["assembled"] == 1
     for u, v in zip(a, c):
         assert np.array_equal(u, v)
+    o = solver.make_opts(rtol=1e-10)
+    o.op = 1
+    out, st, rc = gpu_ctx.solve_batch(mesh2d, SIGMA3, SRC, EVAL, o, raise_on_error=False)
+    assert rc == solver.REMO_ERR_ARG
+    assert all(np.all(np.isnan(u)) for u in out)
 
 
 def _rhs_block(k):
@@ -759,21 +734,16 @@ def test_patch_operator_without_element_locality(mesh3d, gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_operator_choice_by_size(mesh3d, gpu_ctx):
-    """op = "auto" (the default): CSR product while the matrix stays in the Infinity Cache (17 M stored entries), element-wise above;
-    the statistics say which one ran."""
+def test_operator_and_assembly_choice(mesh3d, gpu_ctx):
+    """op = "auto" (the default) in 3D: the patch operator wherever its tables fit; what is assembled beside it follows the size
+    (the whole matrix up to 200 k tetrahedra: inspection hooks at a small cost) or `assemble`; the statistics say which."""
     from remo3d_amd import solver
-    from remo3d_amd import _lib
     _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6))
-    assert rc == 0 and st["op_used"] == 3          # round 3: the patch operator wherever its tables fit
-    _lib.load().remo_debug_tune(20, 0)              # the round-2 rule: by stored entries
-    try:
-        _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6))
-        assert rc == 0 and st["nnz"] < 17000000 and st["op_used"] == 0
-    finally:
-        _lib.load().remo_debug_tune(20, 1)
-    _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, op="element"))
-    assert rc == 0 and st["op_used"] == 1
+    assert rc == 0 and st["op_used"] == 3 and st["assembled"] == 1 and st["nnz"] > 0
+    _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, assemble="vertex_block"))
+    assert rc == 0 and st["op_used"] == 3 and st["assembled"] == 2 and st["nnz"] == 0
+    _, st, rc = gpu_ctx.solve_batch(mesh3d, SIGMA3, SRC[:1], EVAL[:1], solver.make_opts(rtol=1e-6, op="csr"))
+    assert rc == 0 and st["op_used"] == 0 and st["assembled"] == 1
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of one remo_debug_tune key on whole solves of bench batches, alternating the values on the same meshes in one process:
+"""(probe keys need REMO_LIB=remo3d_amd/libremo3d_hip_probes.so: make -C remo3d_amd/csrc probes)
+A/B of one remo_debug_tune key on whole solves of bench batches, alternating the values on the same meshes in one process:
    python tools/ab_tune.py L 23 0 1 [--batches=2]   (key "deg": Chebyshev degree, 0 = default) [--rounds=3] [--precision=fp64]"""
 import os, sys
 import numpy as np
@@ -16,8 +17,11 @@ def main():
     import multiprocessing
     from concurrent.futures import ProcessPoolExecutor
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    with ProcessPoolExecutor(max_workers=min(nb, 8), mp_context=multiprocessing.get_context("spawn")) as pool:   # before the GPU is touched
-        wl = bench.build_workload(0, 1, int(kw.get("depths", 20)), bench.SIZES[size], max_batches=nb, pool=pool if nb > 1 else None)
+    if bench.under_profiler() or nb <= 1:      # behind a preloaded profiler library no child process may start: mesh here (or from the cache)
+        wl = bench.build_workload(0, 1, int(kw.get("depths", 20)), bench.SIZES[size], max_batches=nb)
+    else:
+        with ProcessPoolExecutor(max_workers=min(nb, 8), mp_context=multiprocessing.get_context("spawn")) as pool:   # before the GPU is touched
+            wl = bench.build_workload(0, 1, int(kw.get("depths", 20)), bench.SIZES[size], max_batches=nb, pool=pool)
     print("meshes done: T = %s" % [int(w["mesh"].n_elems) for w in wl["work"]], flush=True)
     from remo3d_amd import _lib, solver
     L = _lib.load()

@@ -471,6 +471,212 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
 #undef REMO_PASSES
 }
 
+// ---- apply, persistent form --------------------------------------------------------------------------------------------------
+// The kernel above is a chain of dependent memory round trips per workgroup: row tables, then x rows, then arithmetic, then stores;
+// four workgroups per CU overlap each other's waits only partly (a workgroup spent 11 k of its 27 k cycles waiting for the two trips).
+// Here a workgroup is PERSISTENT: it walks a contiguous run of patches (XCD-contiguous like the launch above), and everything patch
+// i + 1 needs - its x rows, its row tables (i + 2: the row numbers are the addresses of the x rows), local indices and metric terms of
+// its elements - travels while patch i is being computed, by LDS-DMA (`global_load_lds_dword`: per-lane global address, consecutive LDS
+// words; no registers hold the data, so the arithmetic phase keeps its register budget):
+//   LDS: two row images of (R + 1) k-wide fp64 rows (the image of patch i becomes its accumulators once its values are in
+//        registers, the other one fills with patch i + 1), three slots of row numbers, two of slab slots, two of element data.
+//   per patch: [zero row] barrier | issue the DMA of patch i + 1 (and the row numbers of i + 2) | x values into registers | barrier |
+//        clear accumulators | barrier | tensor chains + ds_add_f64 | s_waitcnt vmcnt(0) (the DMA issued a whole arithmetic phase ago
+//        and the stores of patch i - 1) | barrier | rows out (y or slab) - no wait on memory anywhere but that one, long satisfied.
+// <x, A x> is kept in a register across the patches of the workgroup and leaves it once, at the end.
+// R = the batch's largest row count; the image is sized by it, so two (small patches: three) workgroups share a CU's 160 KB.
+typedef const void __attribute__((address_space(1))) *dma_src_t;
+typedef void __attribute__((address_space(3))) *dma_dst_t;
+
+inline size_t patch_lds_bytes_p(int R, int K, int E) {
+    const size_t Rp = size_t((R + 63) & ~63);
+    return size_t(2) * size_t(R + 1) * size_t(K) * 8 + 5 * Rp * 4 + 2 * (size_t(E) * 40 + size_t(E) * 48) + 64;
+}
+
+template <class T, int K>
+__global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+                                                          double *__restrict__ ppart, const double *__restrict__ scal, int step, double *__restrict__ pbins) {
+    if (scal && solve_done(scal, step)) return;
+    constexpr int BLK = 256, EK = BLK / K, U = kPatchPasses;
+    constexpr uint32_t S = sizeof(T);
+    constexpr int DPR = int(K * S / 4);                  // 4-byte words of a staged row
+    extern __shared__ double lds_raw[];
+    __shared__ double smem[16 * K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Rp = (R + 63) & ~63;
+    const int E = tb.E;
+    double *const Xb0 = lds_raw, *const Xb1 = lds_raw + size_t(R + 1) * K;
+    int32_t *const trow0 = reinterpret_cast<int32_t *>(lds_raw + size_t(2) * size_t(R + 1) * K);   // [3][Rp]
+    int32_t *const tout0 = trow0 + 3 * Rp;                                                          // [2][Rp]
+    uint32_t *const eli0 = reinterpret_cast<uint32_t *>(tout0 + 2 * Rp);                             // [2][E * 10]: local rows, two per word
+    double *const ecm0 = reinterpret_cast<double *>(eli0 + 2 * E * 10);                             // [2][E * 6]: metric terms
+    // this workgroup's run of patches: XCD b & 7 owns one contiguous eighth of the list (neighbouring patches share boundary rows:
+    // the second reader finds them in that L2), its workgroups contiguous runs of the eighth
+    const int64_t per = (tb.npatch + 7) >> 3;
+    const int64_t xb = int64_t(blockIdx.x & 7) * per, xe = (xb + per < tb.npatch) ? xb + per : tb.npatch;
+    const int64_t cnt = xe > xb ? xe - xb : 0;
+    const int64_t nwx = int64_t(gridDim.x >> 3), w = int64_t(blockIdx.x >> 3);
+    const int64_t share = cnt / nwx, extra = cnt % nwx;
+    const int64_t p0 = xb + w * share + (w < extra ? w : extra), p1 = p0 + share + (w < extra ? 1 : 0);
+    if (p0 >= p1) return;                                 // (the whole workgroup)
+
+    // `ndw` consecutive 4-byte words from src to LDS at dst (both wave-uniform), 64 words per wave instruction
+    auto dma_copy = [&](const uint32_t *src, uint32_t *dst, int ndw) {
+        for (int t = wave; t * 64 < ndw; t += 4) {
+            const int j = t * 64 + lane;
+            if (j < ndw) __builtin_amdgcn_global_load_lds((dma_src_t)(src + j), (dma_dst_t)(dst + t * 64), 4, 0, 0);
+        }
+    };
+    // the k-wide x rows named by rowtab[0 .. rows) into the image X: word d of the image = word d % DPR of row rowtab[d / DPR]
+    auto dma_rows = [&](const int32_t *rowtab, double *X, int rows) {
+        const int ndw = rows * DPR;
+        const uint32_t *xw = reinterpret_cast<const uint32_t *>(x);
+        for (int t = wave; t * 64 < ndw; t += 4) {
+            const int d = t * 64 + lane;
+            if (d < ndw) {
+                const int m = int(uint32_t(d) / uint32_t(DPR));
+                const int32_t r = rowtab[m];
+                __builtin_amdgcn_global_load_lds((dma_src_t)(xw + size_t(uint32_t(r)) * DPR + (d - m * DPR)),
+                                                 (dma_dst_t)(reinterpret_cast<uint32_t *>(X) + t * 64), 4, 0, 0);
+            }
+        }
+    };
+    auto dma_elem = [&](int64_t p, int slot) {
+        const int64_t e0 = p * E;
+        const int ne = int(tb.nt - e0 < E ? tb.nt - e0 : E);
+        dma_copy(reinterpret_cast<const uint32_t *>(tb.lidx + e0 * 20), eli0 + slot * E * 10, ne * 10);
+        dma_copy(reinterpret_cast<const uint32_t *>(tb.C + e0 * 6), reinterpret_cast<uint32_t *>(ecm0 + slot * E * 6), ne * 12);
+    };
+    auto prow_of = [&](int64_t p) { return reinterpret_cast<const uint32_t *>(tb.prow + p * tb.rows_cap); };
+    auto pout_of = [&](int64_t p) { return reinterpret_cast<const uint32_t *>(tb.pout + p * tb.rows_cap); };
+    auto clampR = [&](int c) { return c < R ? c : R; };
+
+    int rows_cur = clampR(tb.pcount[p0]);
+    int rows_nxt = (p0 + 1 < p1) ? clampR(tb.pcount[p0 + 1]) : 0;
+    // prologue: tables of the first two patches and the element data of the first, then the first patch's rows (the only exposed trips)
+    dma_copy(prow_of(p0), reinterpret_cast<uint32_t *>(trow0), rows_cur);
+    dma_copy(pout_of(p0), reinterpret_cast<uint32_t *>(tout0), rows_cur);
+    if (p0 + 1 < p1) dma_copy(prow_of(p0 + 1), reinterpret_cast<uint32_t *>(trow0 + Rp), rows_nxt);
+    dma_elem(p0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    dma_rows(trow0, Xb0, rows_cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int el = tid / K, c0 = tid - el * K;
+    const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);
+    const int Rr = tb.spread > 1 ? tb.spread : 1;
+    const int run = el % Rr, rbase = E / Rr, rextra = E % Rr;
+    const int elp = Rr > 1 ? (run * rbase + (run < rextra ? run : rextra) + el / Rr) : el;
+    const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
+    double d0 = 0.0;
+    int slot3 = 0;                                        // slot of the current patch's row numbers (patch number mod 3, without the division)
+    for (int64_t p = p0; p < p1; ++p) {
+        const int it = int(p - p0);
+        double *const Xc = (it & 1) ? Xb1 : Xb0, *const Xn = (it & 1) ? Xb0 : Xb1;
+        T *const xs = reinterpret_cast<T *>(Xc);
+        const int s1 = slot3 == 2 ? 0 : slot3 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        int32_t *const trow_c = trow0 + slot3 * Rp, *const trow_n = trow0 + s1 * Rp, *const trow_nn = trow0 + s2 * Rp;
+        int32_t *const tout_c = tout0 + (it & 1) * Rp, *const tout_n = tout0 + ((it + 1) & 1) * Rp;
+        const int rows_nn = (p + 2 < p1) ? clampR(tb.pcount[p + 2]) : 0;      // (a scalar load: wanted at the next turn)
+        if (tid < K) xs[R * K + tid] = T(0);              // the row constrained dofs read
+        __syncthreads();                                  // B0: X(p) is in LDS (every wave waited for its pieces); the other image and the oldest table slots are free
+        if (p + 1 < p1) {
+            dma_rows(trow_n, Xn, rows_nxt);
+            dma_copy(pout_of(p + 1), reinterpret_cast<uint32_t *>(tout_n), rows_nxt);
+            dma_elem(p + 1, (it + 1) & 1);
+        }
+        if (p + 2 < p1) dma_copy(prow_of(p + 2), reinterpret_cast<uint32_t *>(trow_nn), rows_nn);
+        const int64_t e = p * E + elp;
+        const bool active = el < E && e < tb.nt;
+        const uint32_t *const eli = eli0 + (it & 1) * E * 10 + elp * 10;
+        const double *const ecm = ecm0 + (it & 1) * E * 6 + elp * 6;
+        uint32_t li[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) li[q] = active ? eli[q] : 0u;
+#define REMO_PATCH_L(i) ((li[(i) >> 1] >> (16 * ((i) & 1))) & 0xFFFFu)
+        T xv[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) xv[i] = xs[REMO_PATCH_L(i) * K + c0];
+        __syncthreads();                                  // B1: every lane holds its x values: the image becomes the accumulators
+        double *const ya = Xc;
+        for (int j = tid; j < rows_cur * K; j += BLK) ya[j] = 0.0;
+        if (tid < K) ya[R * K + tid] = 0.0;
+        __syncthreads();                                  // B2
+        if (active) {
+            double cm[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cm[q] = ecm[q];
+            const T c11 = T(cm[0]), c12 = T(cm[1]), c13 = T(cm[2]), c22 = T(cm[3]), c23 = T(cm[4]), c33 = T(cm[5]);
+            T g[30], yv[20];
+            typedef const T __attribute__((address_space(4))) *ctab_t;
+            ctab_t tgrad = (ctab_t)ElemTables<T>::grad(), tdiv = (ctab_t)ElemTables<T>::div();
+            if constexpr (sizeof(T) == 8) { asm volatile("" : "+s"(tgrad)); asm volatile("" : "+s"(tdiv)); }
+            REMO_ELEM_GRAD(T, xv, g, tgrad)
+            T dd = T(0);
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
+                const T g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
+                const T h1 = c11 * g1 + c12 * g2 + c13 * g3, h2 = c12 * g1 + c22 * g2 + c23 * g3, h3 = c13 * g1 + c23 * g2 + c33 * g3;
+                dd += g1 * h1 + g2 * h2 + g3 * h3;
+                g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
+            }
+            d0 += double(dd);
+            REMO_ELEM_DIV(T, g, yv, tdiv)
+#pragma unroll
+            for (int i = 0; i < 20; ++i) lds_add(ya + REMO_PATCH_L(i) * K + c0, double(yv[i]));
+        }
+#undef REMO_PATCH_L
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of patch p + 1 (issued an arithmetic phase ago) and its stores of patch p - 1
+        __syncthreads();                                  // B3: accumulators complete; X(p + 1), tables and element data of p + 1 in LDS
+        {
+            auto put = [&](auto np_c, int m0) {
+                constexpr int NP = decltype(np_c)::value;
+                int32_t r[NP], o[NP];
+                T v[NP][1];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int m = m0 + el + EK * u;
+                    const bool in = m < rows_cur;
+                    r[u] = (in ? trow_c[m] : -1) | off_mask; o[u] = in ? tout_c[m] : -1;
+                    v[u][0] = T(ya[(in ? m : 0) * K + c0]);
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {      // one of the two stores of a value is out of range: dropped by the hardware, no branch
+                    const bool have = r[u] >= 0;
+                    buf_store<T, 1>(ry, (have && o[u] < 0) ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                    buf_store<T, 1>(rb, (have && o[u] >= 0) ? __umul24(uint32_t(o[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                }
+            };
+            const int npass = (rows_cur + EK - 1) / EK;
+            switch (npass) {
+                case 1: put(std::integral_constant<int, 1>{}, 0); break;   case 2: put(std::integral_constant<int, 2>{}, 0); break;
+                case 3: put(std::integral_constant<int, 3>{}, 0); break;   case 4: put(std::integral_constant<int, 4>{}, 0); break;
+                case 5: put(std::integral_constant<int, 5>{}, 0); break;   case 6: put(std::integral_constant<int, 6>{}, 0); break;
+                case 7: put(std::integral_constant<int, 7>{}, 0); break;   case 8: put(std::integral_constant<int, 8>{}, 0); break;
+                case 9: put(std::integral_constant<int, 9>{}, 0); break;   case 10: put(std::integral_constant<int, 10>{}, 0); break;
+                case 11: put(std::integral_constant<int, 11>{}, 0); break; case 12: put(std::integral_constant<int, 12>{}, 0); break;
+                default:
+                    for (int m0 = 0; m0 < rows_cur; m0 += U * EK) put(std::integral_constant<int, U>{}, m0);
+            }
+        }
+        rows_cur = rows_nxt; rows_nxt = rows_nn;
+        slot3 = s1;
+    }
+    if (ppart) {
+        double dot[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
+        block_sum<K>(dot, smem);
+        if (tid < K) {
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[p0 * K + tid] = pick<K>(dot, tid);
+        }
+        if (!pbins)      // one row of sums per PATCH is what the folding launches read: this workgroup's other patches contribute zero
+            for (int64_t j = tid; j < (p1 - p0 - 1) * K; j += BLK) ppart[(p0 + 1) * K + j] = 0.0;
+    }
+}
+
 // Rows shared by several patches: sum of the row's slab slots in ascending patch order.  DOT: the patches' <x, A x> are folded
 // into <= 1024 partial rows for the consumer (every workgroup takes a fixed subset: deterministic given the patches' sums).
 template <class T, int K, bool DOT>
@@ -545,6 +751,10 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 // 158.3 against 153.1 ms per four batches): lean stays the fp32 default.  fp64: 96 registers with spills, five waves: 160 against 156 us.
 int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
+int g_patch_persist = 1;   // remo_debug_tune key 34: 1 = persistent workgroups with LDS-DMA prefetch of the next patch (default), 0 = one workgroup per patch
+void set_patch_persist(int v) { g_patch_persist = v ? 1 : 0; }
+int g_patch_wgs_per_xcd = 0;   // key 35: workgroups per XCD of the persistent kernel (0 = as many as stay resident); tests make small meshes walk several patches per workgroup
+void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
 int g_patch_trim = 1;
 void set_patch_trim(int v) { g_patch_trim = v; }
 int g_patch_spread = 4;
@@ -625,6 +835,27 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
+    if (g_patch_persist && tb.block == 256 && g_patch_mode == 0) {
+        // persistent form: as many workgroups as stay resident (LDS: two row images + tables per workgroup), 32 CUs per XCD
+        const size_t bytes = patch_lds_bytes_p(P.lds_rows, K, tb.E);
+        const size_t lds_cu = 160 * 1024, per_wg = bytes + 16 * K * 8 + 1024;
+        int wpc = int(lds_cu / per_wg);
+        if (wpc > 4) wpc = 4;
+        if (wpc >= 1 && bytes <= 150 * 1024) {
+            static bool attr_ok[2][9] = {};
+            auto kernel = k_patch_apply_p<T, K>;
+            bool &ok = attr_ok[sizeof(T) == 4 ? 1 : 0][K];
+            if (!ok) ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(150 * 1024)) == hipSuccess;
+            if (ok) {
+                int64_t nwx = int64_t(32) * wpc;
+                if (g_patch_wgs_per_xcd > 0 && g_patch_wgs_per_xcd < nwx) nwx = g_patch_wgs_per_xcd;
+                if (nwx > per) nwx = per;
+                if (nwx < 1) nwx = 1;
+                hipLaunchKernelGGL(kernel, dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins);
+                launched = true;
+            }
+        }
+    }
 #ifdef REMO_PROBES      // ablations (wrong results on purpose), the phase probe and 512-thread workgroups: tools/ builds only (make probes)
     if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
         if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {

@@ -69,7 +69,8 @@ def main():
         return x
 
     quick = "--quick" in sys.argv
-    if not quick:
+    vcycle = "--vcycle" in sys.argv
+    if not quick and not vcycle:
         run("jacobi", lambda r: dinv * r)
 
     # current product: Chebyshev(d) on the Jacobi-scaled vertex block, Gershgorin lmax, ratio
@@ -111,6 +112,62 @@ def main():
     for dg, rt in ((deg + 3, ratio * 2), (deg * 2, ratio * 4)):
         run(f"cheb({dg},{rt:.0f}) P1 + jacobi HO", two_level(lambda rv: cheb(rv, dg, rt), ho_jac))
     if quick:
+        print(results)
+        return
+
+    if vcycle:
+        # Round 4: a MULTIPLICATIVE symmetric cycle as the preconditioner of the same PCG, the smoother running on
+        # the FULL matrix-free operator:  z = S r;  z_v += P1 (r - A z)_v;  z += S^T (r - A z)   with S = nu steps of Chebyshev-
+        # accelerated Jacobi on [lmax_A / alpha, lmax_A] (nu = 1: damped Jacobi).  Operator applications per PCG step beside the
+        # PCG's own: 2 nu (nu - 1 inside each smoother, one residual before the P1 correction, one after it).
+        # Priced with the costs measured in round 3 at size L (profiles/r03_sizeL_20depths_kernel_stats_working.txt): operator
+        # application 128 us, a vector pass over n x 5 ~50 us, the P1 chain 90 us, update + direction of the PCG 187 us.
+        lmaxA = float(spla.eigsh(sp.diags(np.sqrt(dinv)) @ A @ sp.diags(np.sqrt(dinv)), k=1, which="LA", return_eigenvectors=False, tol=1e-3)[0]) * 1.02
+        print(f"lmax(D^-1 A) = {lmaxA:.3f}", flush=True)
+
+        def cheb_smooth(r, x0, nu, alpha):
+            """nu steps of Chebyshev-Jacobi for A x = r from x0 (x0 None = 0: the first step needs no product)."""
+            lmin = lmaxA / alpha
+            theta, delta = 0.5 * (lmaxA + lmin), 0.5 * (lmaxA - lmin)
+            sig = theta / delta
+            rho = 1.0 / sig
+            res = r.copy() if x0 is None else r - A @ x0
+            x = np.zeros_like(r) if x0 is None else x0.copy()
+            dd = dinv * res / theta
+            for j in range(nu):
+                x += dd
+                if j == nu - 1:
+                    break
+                res -= A @ dd
+                rho_new = 1.0 / (2.0 * sig - rho)
+                dd = rho_new * rho * dd + 2.0 * rho_new / delta * dinv * res
+                rho = rho_new
+            return x
+
+        def vcyc(p1, nu, alpha):
+            def C(r):
+                z = cheb_smooth(r, None, nu, alpha)                # pre-smoothing from zero: nu - 1 products
+                r1 = r - A @ z                                      # 1 product
+                z[:nvf] += p1(r1[:nvf])
+                return cheb_smooth(r, z, nu, alpha)                # post-smoothing: 1 + (nu - 1) products
+            return C
+
+        base = results.get(f"cheb({deg},{ratio:.0f}) P1 + jacobi HO   [product default]")
+        t_app, t_vec, t_chain, t_pcg_vec = 128.0, 50.0, 90.0, 187.0
+        t_now = t_app + t_pcg_vec + t_chain
+        rows = []
+        for p1name, p1 in (("exact P1", lu.solve), (f"cheb({deg},{ratio:.0f}) P1", lambda rv: cheb(rv, deg, ratio))):
+            for nu in (1, 2, 3):
+                for alpha in ((4.0, 8.0) if nu == 1 else (4.0, 10.0, 30.0)):
+                    name = f"V({nu},{nu}) Chebyshev-Jacobi on the full operator, alpha {alpha:.0f} + {p1name}"
+                    run(name, vcyc(p1, nu, alpha))
+                    it = results[name]
+                    extra = 2 * nu
+                    t_step = t_now + extra * (t_app + t_vec) + 2 * (nu - 1) * t_vec
+                    rows.append((name, it, extra, t_step, it * t_step / (base * t_now)))
+        print("\nsteps, extra applications per PCG step, priced step (us), solve time relative to the product default (%d steps x %.0f us):" % (base, t_now))
+        for name, it, extra, t_step, rel in rows:
+            print(f"  {name:75s} {it:4d} steps  +{extra} applications  {t_step:6.0f} us/step  x{rel:.2f}")
         print(results)
         return
 

@@ -34,6 +34,12 @@ int remo_debug_xcc(remo_ctx_t *ctx, int32_t *out, int32_t nblocks);
  * launch; [9] workgroups.  The last run on the batch must have used the patch operator. */
 int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *batch, int32_t fp32 /* the fp32 instantiation instead */, double *out16);
 
+/* The same for the PERSISTENT form of the kernel (k_patch_apply_p): clock ticks per patch of wave 0, summed by the workgroups over their
+ * patches and averaged - out16[0..8] = barrier B0 | issue of the next patch's LDS-DMA | x values into registers | barrier B1 | clearing + B2 |
+ * tensor chains + LDS accumulation | wait for the DMA and older stores | barrier B3 | rows out; [10] patches, [11] workgroups, [12] ticks of the
+ * busiest workgroup (sum of its phases), [13] microseconds per application without the stamps.  -DREMO_PROBES builds only. */
+int remo_debug_patch_phases_p(remo_ctx_t *ctx, remo_batch_t *batch, int32_t fp32, double *out16);
+
 /* Cost of a grid-wide barrier between the resident workgroups of one launch (nblocks <= 2048 workgroups of 256 threads; nbar
  * iterations of: agent-scope store, barrier, agent-scope load of another workgroup's store, barrier): out3[0] = microseconds per
  * barrier, [1] = 1 if a wait gave up, [2] = loads that did not see the store. */
@@ -53,7 +59,7 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  *   18  0 = elements taken in the caller's order (default 1: sorted by their two smallest vertices);
  *   22  0 = rows shared by patches summed by k_patch_reduce instead of the PCG's update launch;
  *   24  0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image;
- *   34  0 = patch operator with one workgroup per patch (round 3) instead of persistent workgroups that prefetch the next patch by LDS-DMA;
+ *   34  1 = patch operator as persistent workgroups that prefetch the next patch by LDS-DMA (round 4: parity-green, 138 us against 112 at size L: not the default) instead of one workgroup per patch (0);
  *   35  workgroups per XCD of the persistent patch kernel (0 = as many as stay resident): small test meshes walk several patches per workgroup.
  *
  * (b) ONLY IN A LIBRARY BUILT WITH -DREMO_PROBES (`make -C remo3d_amd/csrc probes` -> libremo3d_hip_probes.so, loaded by the tools

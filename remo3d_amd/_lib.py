@@ -54,7 +54,7 @@ EXPORTS = ["remo_abi_version", "remo_opts_default", "remo_ctx_create", "remo_ctx
            "remo_batch_eval", "remo_batch_get_system", "remo_batch_get_vectors", "remo_batch_apply_coarse", "remo_batch_spmv",
            "remo_host_element_matrix", "remo_host_factor_error", "remo_host_symbolic"]
 # include/remo3d_hip_debug.h: probes and tuning knobs (tests, tools, bench.py's `box` record) - not part of the boundary
-DEBUG_EXPORTS = ["remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_cache_gather", "remo_debug_xcc", "remo_debug_tune", "remo_debug_patch_phases", "remo_debug_grid_barrier"]
+DEBUG_EXPORTS = ["remo_debug_stream", "remo_debug_clock", "remo_debug_device", "remo_debug_cache_gather", "remo_debug_xcc", "remo_debug_tune", "remo_debug_patch_phases", "remo_debug_patch_phases_p", "remo_debug_grid_barrier"]
 
 _lib = None
 
@@ -97,6 +97,8 @@ def load():
     L.remo_batch_apply_coarse.argtypes = [vp, vp, C.c_int32, dp, dp, C.c_int32, i64p]
     L.remo_debug_patch_phases.restype = C.c_int
     L.remo_debug_patch_phases.argtypes = [vp, vp, C.c_int32, dp]
+    L.remo_debug_patch_phases_p.restype = C.c_int
+    L.remo_debug_patch_phases_p.argtypes = [vp, vp, C.c_int32, dp]
     L.remo_debug_grid_barrier.restype = C.c_int
     L.remo_debug_grid_barrier.argtypes = [vp, C.c_int32, C.c_int32, dp]
     L.remo_debug_xcc.restype = C.c_int

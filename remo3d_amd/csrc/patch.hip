@@ -493,10 +493,22 @@ inline size_t patch_lds_bytes_p(int R, int K, int E) {
     return size_t(2) * size_t(R + 1) * size_t(K) * 8 + 5 * Rp * 4 + 2 * (size_t(E) * 40 + size_t(E) * 48) + 64;
 }
 
-template <class T, int K>
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() is fence + barrier, and the fence drains the
+// vector-memory counter too (`s_waitcnt vmcnt(0) lgkmcnt(0)` in the ISA): inside the persistent loop that would wait, at the first
+// barrier of a patch, for the stores of the patch before it and, at the second, for the LDS-DMA just issued for the next one -
+// exactly the two round trips the loop exists to hide (measured: 7.5 k of 20.6 k clock ticks per patch sat in that first barrier).
+// Data that crosses the barrier here lives in LDS (ordered by lgkmcnt(0)); what the DMA brings is ordered by the explicit
+// `s_waitcnt vmcnt(0)` before barrier B3; nothing a wave stores to global memory is read by another wave of the launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class T, int K, bool STAMP = false>
 __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
-                                                          double *__restrict__ ppart, const double *__restrict__ scal, int step, double *__restrict__ pbins) {
+                                                          double *__restrict__ ppart, const double *__restrict__ scal, int step, double *__restrict__ pbins,
+                                                          long long *__restrict__ stamps) {
     if (scal && solve_done(scal, step)) return;
+    // STAMP (probe builds, remo_debug_patch_phases): wave 0 sums the clock ticks of every phase over the workgroup's patches
+    long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
+#define REMO_PH(k) if constexpr (STAMP) { const long long now_ = __builtin_readcyclecounter(); ph[k] += now_ - tk; tk = now_; }
     constexpr int BLK = 256, EK = BLK / K, U = kPatchPasses;
     constexpr uint32_t S = sizeof(T);
     constexpr int DPR = int(K * S / 4);                  // 4-byte words of a staged row
@@ -517,7 +529,10 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
     const int64_t cnt = xe > xb ? xe - xb : 0;
     const int64_t nwx = int64_t(gridDim.x >> 3), w = int64_t(blockIdx.x >> 3);
     const int64_t share = cnt / nwx, extra = cnt % nwx;
-    const int64_t p0 = xb + w * share + (w < extra ? w : extra), p1 = p0 + share + (w < extra ? 1 : 0);
+    const int64_t p0_ = xb + w * share + (w < extra ? w : extra);
+    // (patch numbers in scalar registers: the row counts of the patches ahead are then scalar loads - a vector load here would be waited
+    // for on the spot, together with every store still in flight)
+    const int p0 = __builtin_amdgcn_readfirstlane(int(p0_)), p1 = __builtin_amdgcn_readfirstlane(int(p0_ + share + (w < extra ? 1 : 0)));
     if (p0 >= p1) return;                                 // (the whole workgroup)
 
     // `ndw` consecutive 4-byte words from src to LDS at dst (both wave-uniform), 64 words per wave instruction
@@ -527,36 +542,64 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
             if (j < ndw) __builtin_amdgcn_global_load_lds((dma_src_t)(src + j), (dma_dst_t)(dst + t * 64), 4, 0, 0);
         }
     };
-    // the k-wide x rows named by rowtab[0 .. rows) into the image X: word d of the image = word d % DPR of row rowtab[d / DPR]
+    // the same in 16-byte pieces (1 KB per wave instruction) for sources and destinations aligned to 16 bytes; the tail in 4-byte words
+    auto dma_copy16 = [&](const uint32_t *src, uint32_t *dst, int ndw) {
+        const int n16 = ndw >> 2;
+        for (int t = wave; t * 64 < n16; t += 4) {
+            const int j = t * 64 + lane;
+            if (j < n16) __builtin_amdgcn_global_load_lds((dma_src_t)(src + 4 * j), (dma_dst_t)(dst + t * 256), 16, 0, 0);
+        }
+        const int tail = ndw & 3;
+        if (wave == 3 && lane < tail) __builtin_amdgcn_global_load_lds((dma_src_t)(src + 4 * n16 + lane), (dma_dst_t)(dst + 4 * n16), 4, 0, 0);
+    };
+    // the k-wide x rows named by rowtab[0 .. rows) into the image X: word d of the image = word d % DPR of row rowtab[d / DPR].
+    // The row numbers of UN pieces are read from LDS together, then the UN pieces leave back to back: one piece at a time, its row
+    // number's LDS latency in front of every instruction, cost a wave ~300 clock ticks per piece (7 k ticks per patch: measured)
     auto dma_rows = [&](const int32_t *rowtab, double *X, int rows) {
         const int ndw = rows * DPR;
         const uint32_t *xw = reinterpret_cast<const uint32_t *>(x);
-        for (int t = wave; t * 64 < ndw; t += 4) {
-            const int d = t * 64 + lane;
-            if (d < ndw) {
+        constexpr int UN = 6;
+        for (int t0 = wave; t0 * 64 < ndw; t0 += 4 * UN) {
+            uint32_t r[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int d = (t0 + 4 * u) * 64 + lane;
                 const int m = int(uint32_t(d) / uint32_t(DPR));
-                const int32_t r = rowtab[m];
-                __builtin_amdgcn_global_load_lds((dma_src_t)(xw + size_t(uint32_t(r)) * DPR + (d - m * DPR)),
-                                                 (dma_dst_t)(reinterpret_cast<uint32_t *>(X) + t * 64), 4, 0, 0);
+                r[u] = uint32_t(rowtab[m < rows ? m : rows - 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int t = t0 + 4 * u, d = t * 64 + lane;
+                if (d < ndw) {
+                    const int m = int(uint32_t(d) / uint32_t(DPR));
+                    const uint32_t rr = r[u] < uint32_t(tb.n) ? r[u] : 0u;     // (never out of range by construction; a source address must not depend on that)
+                    __builtin_amdgcn_global_load_lds((dma_src_t)(xw + size_t(rr) * DPR + (d - m * DPR)),
+                                                     (dma_dst_t)(reinterpret_cast<uint32_t *>(X) + t * 64), 4, 0, 0);
+                }
             }
         }
     };
-    auto dma_elem = [&](int64_t p, int slot) {
-        const int64_t e0 = p * E;
+    auto dma_elem = [&](int p, int slot) {
+        const int64_t e0 = int64_t(p) * E;
         const int ne = int(tb.nt - e0 < E ? tb.nt - e0 : E);
         dma_copy(reinterpret_cast<const uint32_t *>(tb.lidx + e0 * 20), eli0 + slot * E * 10, ne * 10);
-        dma_copy(reinterpret_cast<const uint32_t *>(tb.C + e0 * 6), reinterpret_cast<uint32_t *>(ecm0 + slot * E * 6), ne * 12);
+        dma_copy16(reinterpret_cast<const uint32_t *>(tb.C + e0 * 6), reinterpret_cast<uint32_t *>(ecm0 + slot * E * 6), ne * 12);
     };
-    auto prow_of = [&](int64_t p) { return reinterpret_cast<const uint32_t *>(tb.prow + p * tb.rows_cap); };
-    auto pout_of = [&](int64_t p) { return reinterpret_cast<const uint32_t *>(tb.pout + p * tb.rows_cap); };
+    const bool tab16 = (tb.rows_cap & 3) == 0;          // a patch's tables start on 16 bytes
+    auto dma_tab = [&](const uint32_t *src, uint32_t *dst, int n) { if (tab16) dma_copy16(src, dst, n); else dma_copy(src, dst, n); };
+    auto prow_of = [&](int p) { return reinterpret_cast<const uint32_t *>(tb.prow + int64_t(p) * tb.rows_cap); };
+    auto pout_of = [&](int p) { return reinterpret_cast<const uint32_t *>(tb.pout + int64_t(p) * tb.rows_cap); };
     auto clampR = [&](int c) { return c < R ? c : R; };
 
-    int rows_cur = clampR(tb.pcount[p0]);
-    int rows_nxt = (p0 + 1 < p1) ? clampR(tb.pcount[p0 + 1]) : 0;
+    // (the row counts through the constant address space: invariant during the launch, so the loads are scalar loads even behind stores)
+    typedef const int32_t __attribute__((address_space(4))) *cint_t;
+    const cint_t pcnt = (cint_t)tb.pcount;
+    int rows_cur = clampR(pcnt[p0]);
+    int rows_nxt = (p0 + 1 < p1) ? clampR(pcnt[p0 + 1]) : 0;
     // prologue: tables of the first two patches and the element data of the first, then the first patch's rows (the only exposed trips)
-    dma_copy(prow_of(p0), reinterpret_cast<uint32_t *>(trow0), rows_cur);
-    dma_copy(pout_of(p0), reinterpret_cast<uint32_t *>(tout0), rows_cur);
-    if (p0 + 1 < p1) dma_copy(prow_of(p0 + 1), reinterpret_cast<uint32_t *>(trow0 + Rp), rows_nxt);
+    dma_tab(prow_of(p0), reinterpret_cast<uint32_t *>(trow0), rows_cur);
+    dma_tab(pout_of(p0), reinterpret_cast<uint32_t *>(tout0), rows_cur);
+    if (p0 + 1 < p1) dma_tab(prow_of(p0 + 1), reinterpret_cast<uint32_t *>(trow0 + Rp), rows_nxt);
     dma_elem(p0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -569,25 +612,38 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
     const int run = el % Rr, rbase = E / Rr, rextra = E % Rr;
     const int elp = Rr > 1 ? (run * rbase + (run < rextra ? run : rextra) + el / Rr) : el;
     const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
+    // y and the slab are two ranges of one arena: when both fit one buffer descriptor (4 GB of byte offsets) a value needs ONE store
+    // instruction with the destination chosen by offset, not two of which the hardware drops one - the output phase is bound by the
+    // ISSUE of its stores (the waves of a workgroup queue behind each other in it)
+    const char *const lo_ = reinterpret_cast<const char *>(y) < reinterpret_cast<const char *>(Yb) ? reinterpret_cast<const char *>(y) : reinterpret_cast<const char *>(Yb);
+    const uint64_t y_off64 = uint64_t(reinterpret_cast<const char *>(y) - lo_), b_off64 = uint64_t(reinterpret_cast<const char *>(Yb) - lo_);
+    const uint64_t span = (y_off64 + uint64_t(tb.n) * K * S > b_off64 + uint64_t(tb.nslot_cap) * K * S) ? y_off64 + uint64_t(tb.n) * K * S : b_off64 + uint64_t(tb.nslot_cap) * K * S;
+    const bool one_desc = span < 0xFFFFF000ull;
+    const rsrc_t rboth = make_rsrc(lo_, one_desc ? span : 0);
+    const uint32_t y_off = uint32_t(y_off64), b_off = uint32_t(b_off64);
     double d0 = 0.0;
     int slot3 = 0;                                        // slot of the current patch's row numbers (patch number mod 3, without the division)
-    for (int64_t p = p0; p < p1; ++p) {
-        const int it = int(p - p0);
+    for (int p = p0; p < p1; ++p) {
+        const int it = p - p0;
         double *const Xc = (it & 1) ? Xb1 : Xb0, *const Xn = (it & 1) ? Xb0 : Xb1;
         T *const xs = reinterpret_cast<T *>(Xc);
         const int s1 = slot3 == 2 ? 0 : slot3 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
         int32_t *const trow_c = trow0 + slot3 * Rp, *const trow_n = trow0 + s1 * Rp, *const trow_nn = trow0 + s2 * Rp;
         int32_t *const tout_c = tout0 + (it & 1) * Rp, *const tout_n = tout0 + ((it + 1) & 1) * Rp;
-        const int rows_nn = (p + 2 < p1) ? clampR(tb.pcount[p + 2]) : 0;      // (a scalar load: wanted at the next turn)
+        const int rows_nn = (p + 2 < p1) ? clampR(pcnt[p + 2]) : 0;           // (a scalar load: wanted at the next turn)
+        if constexpr (STAMP) tk = __builtin_readcyclecounter();
         if (tid < K) xs[R * K + tid] = T(0);              // the row constrained dofs read
-        __syncthreads();                                  // B0: X(p) is in LDS (every wave waited for its pieces); the other image and the oldest table slots are free
+        if constexpr (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); REMO_PH(9) }      // (probe: this wave's own LDS / scalar operations, apart from the barrier)
+        lds_barrier();                                   // B0: X(p) is in LDS (every wave waited for its pieces); the other image and the oldest table slots are free
+        REMO_PH(0)                                          // barrier B0
         if (p + 1 < p1) {
             dma_rows(trow_n, Xn, rows_nxt);
-            dma_copy(pout_of(p + 1), reinterpret_cast<uint32_t *>(tout_n), rows_nxt);
+            dma_tab(pout_of(p + 1), reinterpret_cast<uint32_t *>(tout_n), rows_nxt);
             dma_elem(p + 1, (it + 1) & 1);
         }
-        if (p + 2 < p1) dma_copy(prow_of(p + 2), reinterpret_cast<uint32_t *>(trow_nn), rows_nn);
-        const int64_t e = p * E + elp;
+        if (p + 2 < p1) dma_tab(prow_of(p + 2), reinterpret_cast<uint32_t *>(trow_nn), rows_nn);
+        REMO_PH(1)                                          // DMA issue
+        const int64_t e = int64_t(p) * E + elp;
         const bool active = el < E && e < tb.nt;
         const uint32_t *const eli = eli0 + (it & 1) * E * 10 + elp * 10;
         const double *const ecm = ecm0 + (it & 1) * E * 6 + elp * 6;
@@ -598,11 +654,14 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
         T xv[20];
 #pragma unroll
         for (int i = 0; i < 20; ++i) xv[i] = xs[REMO_PATCH_L(i) * K + c0];
-        __syncthreads();                                  // B1: every lane holds its x values: the image becomes the accumulators
+        REMO_PH(2)                                          // x values into registers
+        lds_barrier();                                   // B1: every lane holds its x values: the image becomes the accumulators
+        REMO_PH(3)
         double *const ya = Xc;
         for (int j = tid; j < rows_cur * K; j += BLK) ya[j] = 0.0;
         if (tid < K) ya[R * K + tid] = 0.0;
-        __syncthreads();                                  // B2
+        lds_barrier();                                   // B2
+        REMO_PH(4)                                          // clearing + B2
         if (active) {
             double cm[6];
 #pragma unroll
@@ -627,9 +686,13 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
             for (int i = 0; i < 20; ++i) lds_add(ya + REMO_PATCH_L(i) * K + c0, double(yv[i]));
         }
 #undef REMO_PATCH_L
+        REMO_PH(5)                                          // tensor chains + LDS accumulation
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of patch p + 1 (issued an arithmetic phase ago) and its stores of patch p - 1
-        __syncthreads();                                  // B3: accumulators complete; X(p + 1), tables and element data of p + 1 in LDS
-        {
+        REMO_PH(6)                                          // wait for the DMA / older stores
+        lds_barrier();                                   // B3: accumulators complete; X(p + 1), tables and element data of p + 1 in LDS
+        REMO_PH(7)
+        auto rows_out = [&](auto one_c) {
+            constexpr bool ONE_STORE = decltype(one_c)::value;
             auto put = [&](auto np_c, int m0) {
                 constexpr int NP = decltype(np_c)::value;
                 int32_t r[NP], o[NP];
@@ -642,10 +705,16 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
                     v[u][0] = T(ya[(in ? m : 0) * K + c0]);
                 }
 #pragma unroll
-                for (int u = 0; u < NP; ++u) {      // one of the two stores of a value is out of range: dropped by the hardware, no branch
-                    const bool have = r[u] >= 0;
-                    buf_store<T, 1>(ry, (have && o[u] < 0) ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
-                    buf_store<T, 1>(rb, (have && o[u] >= 0) ? __umul24(uint32_t(o[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                for (int u = 0; u < NP; ++u) {
+                    if constexpr (ONE_STORE) {      // ONE store per value: y and the slab through one descriptor (base = the lower of the two)
+                        const bool have = r[u] >= 0;
+                        const uint32_t off = o[u] < 0 ? y_off + __umul24(uint32_t(r[u]), K * S) : b_off + __umul24(uint32_t(o[u]), K * S);
+                        buf_store<T, 1>(rboth, have ? off + uint32_t(c0) * S : kOutOfRange, v[u]);
+                    } else {                        // one of the two stores of a value is out of range: dropped by the hardware, no branch
+                        const bool have = r[u] >= 0;
+                        buf_store<T, 1>(ry, (have && o[u] < 0) ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                        buf_store<T, 1>(rb, (have && o[u] >= 0) ? __umul24(uint32_t(o[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+                    }
                 }
             };
             const int npass = (rows_cur + EK - 1) / EK;
@@ -659,10 +728,22 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
                 default:
                     for (int m0 = 0; m0 < rows_cur; m0 += U * EK) put(std::integral_constant<int, U>{}, m0);
             }
-        }
+        };
+        if (one_desc) rows_out(std::true_type{}); else rows_out(std::false_type{});
+        REMO_PH(8)                                          // rows out
         rows_cur = rows_nxt; rows_nxt = rows_nn;
         slot3 = s1;
     }
+    if constexpr (STAMP) {
+#ifndef REMO_STAMP_WAVE
+#define REMO_STAMP_WAVE 0        /* which wave of the workgroup reports (the waves queue behind each other in the output phase) */
+#endif
+        if (tid == 64 * REMO_STAMP_WAVE) {
+            for (int k = 0; k < 10; ++k) stamps[int64_t(blockIdx.x) * 12 + k] = ph[k];
+            stamps[int64_t(blockIdx.x) * 12 + 10] = p1 - p0;
+        }
+    }
+#undef REMO_PH
     if (ppart) {
         double dot[K];
 #pragma unroll
@@ -670,10 +751,10 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
         block_sum<K>(dot, smem);
         if (tid < K) {
             if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else ppart[p0 * K + tid] = pick<K>(dot, tid);
+            else ppart[int64_t(p0) * K + tid] = pick<K>(dot, tid);
         }
         if (!pbins)      // one row of sums per PATCH is what the folding launches read: this workgroup's other patches contribute zero
-            for (int64_t j = tid; j < (p1 - p0 - 1) * K; j += BLK) ppart[(p0 + 1) * K + j] = 0.0;
+            for (int64_t j = tid; j < int64_t(p1 - p0 - 1) * K; j += BLK) ppart[int64_t(p0 + 1) * K + j] = 0.0;
     }
 }
 
@@ -751,7 +832,15 @@ void set_patch_stamps(long long *buf) { g_patch_stamps = buf; }
 // 158.3 against 153.1 ms per four batches): lean stays the fp32 default.  fp64: 96 registers with spills, five waves: 160 against 156 us.
 int g_patch_lean = -1;
 void set_patch_lean(int v) { g_patch_lean = v; }
-int g_patch_persist = 1;   // remo_debug_tune key 34: 1 = persistent workgroups with LDS-DMA prefetch of the next patch (default), 0 = one workgroup per patch
+// remo_debug_tune key 34: 1 = persistent workgroups with LDS-DMA prefetch of the next patch, 0 = one workgroup per patch (default).
+// Measured at size L (370 k tetrahedra, k = 5, fp64; profiles/r04_h_*): the persistent form is parity-green and removes every wait on
+// memory from the loop (the wait before barrier B3 costs 8 clock ticks) but takes 138 us per application against 112: its LDS (two
+// row images + tables: 65 KB) leaves two workgroups per CU, a wave spends 5.9 k of its 18.7 k ticks per patch ISSUING the ~25 LDS-DMA
+// instructions of the next patch (4-byte pieces - 40-byte rows do not tile into 16-byte ones - cost ~240 ticks each), and the tensor
+// chains (7.5 k) are bound by the fp64 rate whenever the CU's two workgroups are in them together.  With two contexts on the GPU the
+// two forms give the same points/s (115.9 against 115.3).  Kept for that record and as the starting point of a version with
+// 16-byte-tiled rows; not the default.
+int g_patch_persist = 0;
 void set_patch_persist(int v) { g_patch_persist = v ? 1 : 0; }
 int g_patch_wgs_per_xcd = 0;   // key 35: workgroups per XCD of the persistent kernel (0 = as many as stay resident); tests make small meshes walk several patches per workgroup
 void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
@@ -835,7 +924,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
-    if (g_patch_persist && tb.block == 256 && g_patch_mode == 0) {
+    if (g_patch_persist && tb.block == 256 && (g_patch_mode == 0 || g_patch_mode == 4)) {
         // persistent form: as many workgroups as stay resident (LDS: two row images + tables per workgroup), 32 CUs per XCD
         const size_t bytes = patch_lds_bytes_p(P.lds_rows, K, tb.E);
         const size_t lds_cu = 160 * 1024, per_wg = bytes + 16 * K * 8 + 1024;
@@ -851,14 +940,21 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
                 if (g_patch_wgs_per_xcd > 0 && g_patch_wgs_per_xcd < nwx) nwx = g_patch_wgs_per_xcd;
                 if (nwx > per) nwx = per;
                 if (nwx < 1) nwx = 1;
-                hipLaunchKernelGGL(kernel, dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins);
+#ifdef REMO_PROBES
+                if (g_patch_stamps && K == 5) {
+                    auto ks = k_patch_apply_p<T, K, true>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(150 * 1024));
+                    hipLaunchKernelGGL(ks, dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins, g_patch_stamps);
+                } else
+#endif
+                hipLaunchKernelGGL(kernel, dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins, (long long *)nullptr);
                 launched = true;
             }
         }
     }
 #ifdef REMO_PROBES      // ablations (wrong results on purpose), the phase probe and 512-thread workgroups: tools/ builds only (make probes)
     if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
-        if (g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
+        if (!launched && g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {
             launched = true;
             if (tb.block == 512) {
                 if (g_patch_mode == 1) launch(k_patch_apply<T, 5, 512, 1>, 512);

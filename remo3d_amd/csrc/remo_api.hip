@@ -1316,6 +1316,7 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, doub
         HIP_TRY(hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(st, 0, sizeof(long long) * grid * 8));
         const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
+        set_patch_persist(0);     // (this probe is about the one-workgroup-per-patch form; remo_debug_patch_phases_p is the persistent one's)
         set_patch_stamps(st); set_patch_mode(4);
         if (fp32) {     // the fp32 instantiation on the same tables (vectors reinterpreted: timing only)
             CsrViewT<float> A32{n, 0, nullptr, nullptr, nullptr};
@@ -1364,6 +1365,73 @@ int remo_debug_patch_phases(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, doub
         for (int q = 0; q < 8; ++q) out16[q] /= double(cnt > 0 ? cnt : 1);
         out16[8] = double(hi - lo);     // first start to last end, clock ticks
         out16[9] = double(cnt);
+        set_patch_persist(1);
+        return REMO_OK;
+    } catch (const std::exception &ex) {
+        set_patch_mode(0); set_patch_stamps(nullptr); set_patch_persist(1);
+        if (dx) (void)hipFree(dx);
+        if (dy) (void)hipFree(dy);
+        if (st) (void)hipFree(st);
+        return fail(ctx, REMO_ERR_DEVICE, ex.what());
+    }
+#endif
+}
+
+int remo_debug_patch_phases_p(remo_ctx_t *ctx, remo_batch_t *b, int32_t fp32, double *out16) {
+    if (!ctx || !b || !out16) return REMO_ERR_ARG;
+#ifndef REMO_PROBES
+    (void)fp32;
+    return fail(ctx, REMO_ERR_ARG, "remo_debug_patch_phases_p: the library was built without -DREMO_PROBES (make -C remo3d_amd/csrc probes)");
+#else
+    if (!b->has_system || b->run_id != ctx->run_id || !b->A.patch) return fail(ctx, REMO_ERR_ARG, "the last run on this batch did not use the patch operator");
+    const int k = 5;
+    if (k * b->patch64.t.E > b->patch64.t.block) return fail(ctx, REMO_ERR_ARG, "the batch's patch tables are laid out for fewer than 5 columns");
+    double *dx = nullptr, *dy = nullptr;
+    long long *st = nullptr;
+    const int64_t slots = 8192;      // workgroups the stamp buffer holds
+    try {
+        HIP_TRY(hipSetDevice(ctx->device));
+        const int64_t n = b->A.n;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * (n * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dy), sizeof(double) * (n * k + 2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st), sizeof(long long) * slots * 12));
+        std::vector<double> hx(size_t(n) * k);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = double((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+        HIP_TRY(hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(st, 0, sizeof(long long) * slots * 12));
+        const int nb = spmv_grid(n, choose_lanes_per_row(n, b->A.nnz));
+        CsrViewT<float> A32{n, 0, nullptr, nullptr, nullptr};
+        PatchOpT<float> P32{b->patch64.t, reinterpret_cast<float *>(b->patch64.Yb), b->patch64.ppart, b->patch64.lds_rows};
+        A32.patch = &P32; A32.vertex_block_only = true;
+        auto once = [&]() {
+            if (fp32) launch_spmm(A32, k, reinterpret_cast<const float *>(dx), reinterpret_cast<float *>(dy), nullptr, nullptr, nb, ctx->stream);
+            else launch_spmm(b->A, k, dx, dy, nullptr, nullptr, nb, ctx->stream);
+        };
+        set_patch_stamps(st); set_patch_mode(4);
+        for (int rep = 0; rep < 3; ++rep) once();
+        set_patch_mode(0); set_patch_stamps(nullptr);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        once();
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        for (int rep = 0; rep < 10; ++rep) once();
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+        std::vector<long long> h(size_t(slots) * 12);
+        HIP_TRY(hipMemcpy(h.data(), st, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(st);
+        for (int i = 0; i < 16; ++i) out16[i] = 0.0;
+        double patches = 0, wgs = 0, longest = 0;
+        for (int64_t w = 0; w < slots; ++w) {
+            const long long *s12 = h.data() + w * 12;
+            if (s12[10] <= 0) continue;
+            double tot = 0;
+            for (int q = 0; q < 10; ++q) { out16[q] += double(s12[q]); tot += double(s12[q]); }
+            patches += double(s12[10]); wgs += 1; longest = std::max(longest, tot);
+        }
+        for (int q = 0; q < 10; ++q) out16[q] /= (patches > 0 ? patches : 1);     // clock ticks per patch, phase by phase
+        out16[10] = patches; out16[11] = wgs; out16[12] = longest; out16[13] = 1e3 * double(ms) / 10.0;
         return REMO_OK;
     } catch (const std::exception &ex) {
         set_patch_mode(0); set_patch_stamps(nullptr);

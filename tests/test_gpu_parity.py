@@ -613,9 +613,9 @@ def test_patch_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 3, 5, 8])
 def test_persistent_patch_kernel_is_the_same_operator(k, mesh3d, gpu_ctx):
-    """The patch operator's two launch forms - one workgroup per patch (remo_debug_tune key 34 = 0, round 3) and persistent workgroups
-    that walk a run of patches while the next patch's rows, tables and element data arrive by LDS-DMA (the default) - are the same
-    operator: products agree with each other, with the CSR product and with the oracle's to rounding, also when a workgroup walks
+    """The patch operator's two launch forms - one workgroup per patch (the default) and persistent workgroups that walk a run of
+    patches while the next patch's rows, tables and element data arrive by LDS-DMA (remo_debug_tune key 34 = 1; round 4: measured
+    slower in isolation, level under two contexts, kept as an option) - are the same operator: products agree with each other, with the CSR product and with the oracle's to rounding, also when a workgroup walks
     MANY patches (key 35: few workgroups per XCD; the small test mesh would otherwise give every workgroup one patch and never
     reach the prefetch) or exactly one or two, in fp64 and through a mixed-precision solve."""
     from remo3d_amd import _lib, solver
@@ -647,7 +647,7 @@ def test_persistent_patch_kernel_is_the_same_operator(k, mesh3d, gpu_ctx):
                 L.remo_debug_tune(34, 1)
                 assert np.allclose(u1, u0, rtol=1e-8 if precision == "fp64" else 3e-7, atol=0), (wgs, precision)
     finally:
-        L.remo_debug_tune(34, 1); L.remo_debug_tune(35, 0)
+        L.remo_debug_tune(34, 0); L.remo_debug_tune(35, 0)
         b.close()
 
 

@@ -12,7 +12,7 @@ the image), size L = 1.2 x that field; their sizes (T, n, nnz) are printed in th
 One "step" = one pass of the hot path over every batch of the sweep, the way the product runs it
 (`Model` / worker.py:74-142): per batch host arrays -> device (remo_solve_batch), dof numbering, the
 assembly the operator needs, multi-RHS two-level PCG, axis evaluation, potentials -> host, apparent
-resistivity — TWO contexts per GPU (streams + arenas, one host thread each) take the batches in turn, as
+resistivity — THREE contexts per GPU (streams + arenas, one host thread each) take the batches in turn, as
 `Model` does by default — then ONE all-reduce of the log slab across ranks (RCCL).  The timed span is
 SURVEY.md 8d's: H2D of the mesh arrays ... D2H of the potentials; mesh generation is excluded (8d) and
 reported beside it.  `value` comes from that span.  Per-kernel figures (`roofline`, `breakdown`) come
@@ -320,7 +320,8 @@ def pmc_traffic(workload, op="csr"):
         return None
     size = re.search(r"mesh size (\w+)", workload or "")
     if size and p.get("mesh_size") == size.group(1) and p.get("operator", "csr") == op:
-        return dict(bytes=p["spmm"]["traffic_bytes_per_launch"], n_free=p.get("n_free"), mesh_T=p.get("mesh_T"))
+        return dict(bytes=p["spmm"]["traffic_bytes_per_launch"], n_free=p.get("n_free"), mesh_T=p.get("mesh_T"),
+                    algorithmic=p.get("algorithmic_bytes_per_launch_same_launches"), workload=p.get("workload"))
     return None
 
 
@@ -497,8 +498,8 @@ def roofline_of(agg, precision, stride, workload_name=None, contexts=1):
     r = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
              traffic=tr["bytes"] if tr else None)
     if tr:     # the counter passes ran on the first batches of the SAME sweep (meshes from the on-disk cache): compare like with like
-        alg = (16.0 * 5 * tr["n_free"] + 88.0 * tr["mesh_T"]) if op == "patch" and tr.get("n_free") and tr.get("mesh_T") else None
-        r["traffic_measured_on"] = dict(n_free=tr.get("n_free"), mesh_T=tr.get("mesh_T"), algorithmic_bytes_there=alg,
+        alg = tr.get("algorithmic") or ((16.0 * 5 * tr["n_free"] + 88.0 * tr["mesh_T"]) if op == "patch" and tr.get("n_free") and tr.get("mesh_T") else None)
+        r["traffic_measured_on"] = dict(workload=tr.get("workload"), algorithmic_bytes_there=alg,
                                         traffic_over_algorithmic=(tr["bytes"] / alg) if alg else None, file=PMC_FILE,
                                         note="committed rocprofv3 --pmc passes (tools/collect_traffic.sh), not measured in this run")
     prec = "fp64" if precision == "fp64" else "fp32 values and vectors"
@@ -530,7 +531,7 @@ def roofline_of(agg, precision, stride, workload_name=None, contexts=1):
 def model_end_to_end(n_depths, cpu_workers):
     """BASELINE configs[2] through the product's front door: Model.compute_synthetic_logs on Benchmark model 3 (dip 30), both tools,
     `n_depths` depths - interface-conforming meshes at the default scale built by `cpu_workers` mesh processes AHEAD of the solver,
-    two contexts on the GPU, uploads, solves, apparent resistivities.  Everything a user waits for is inside the span."""
+    Model's default number of contexts on the GPU, uploads, solves, apparent resistivities.  Everything a user waits for is inside the span."""
     import numpy as np
     from remo3d_amd.model import Model
     ex = os.path.join(ROOT, "tests", "golden", "examples", "Benchmark models", "Benchmark model 3")
@@ -543,7 +544,7 @@ def model_end_to_end(n_depths, cpu_workers):
     pts = n_depths * len(TOOLS)
     nan = int(sum(np.isnan(v[:, 1]).sum() for v in m.logs.values()))
     return dict(value=pts / dt, unit="points/s", points=pts, seconds=dt, includes="mesh generation (interface-conforming revolved meshes, scale 1.0, %d mesh processes ahead of the solver), "
-                "host -> device, numbering, assembly, PCG, evaluation, device -> host, apparent resistivity; two contexts on the GPU" % min(int(cpu_workers), 8),
+                "host -> device, numbering, assembly, PCG, evaluation, device -> host, apparent resistivity; Model's default number of contexts on the GPU" % min(int(cpu_workers), 8),
                 batches=t.get("batches"), pcg_steps_per_batch=(t.get("pcg_steps", 0) / max(1, t.get("batches", 1))), busy_s=t.get("busy_s"),
                 sum_of_mesh_waits_s=t.get("mesh_s"), sum_of_solve_calls_s=t.get("solve_s"), failed_batches=t.get("failed_batches"), nan_points=nan)
 
@@ -590,9 +591,9 @@ def main():
     ap.add_argument("--op", default="auto", choices=["auto", "csr", "patch"],
                     help="how the CG applies A: csr = SpMM on the assembled matrix; patch = matrix-free through the factorised reference tensors, "
                          "patch by patch with LDS-staged vectors; auto (the library's default) = patch in 3D")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
-                         "2 = the headline configuration and Model's default (the launch-latency-bound part of one batch's PCG step is filled by the other's kernels)")
+                         "3 = the headline configuration and Model's default, model.DEFAULT_CONTEXTS (the launch-latency-bound part of one batch's PCG step is filled by the others' kernels)")
     ap.add_argument("--resident", action="store_true",
                     help="headline leg with the batches resident on the device before the timed region (remo_batch_create) instead of SURVEY 8d's span "
                          "(host arrays -> device inside it); per-kernel profiling runs use this with --streams 1")
@@ -789,7 +790,7 @@ def main():
             log("kernel-timing leg (one context, resident) done: %.3f s" % dt_k)
         out["roofline"] = roofline_of(agg_k, args.precision, stride, workload_name, contexts=1)
         out["roofline"]["measured_in"] = ("the headline leg" if agg_k is agg else
-                                          "a single-context leg of the same batches, resident, %d step(s) right after the headline leg: kernels of two contexts share the chip, "
+                                          "a single-context leg of the same batches, resident, %d step(s) right after the headline leg: kernels of several contexts share the chip, "
                                           "so the headline leg's own brackets (roofline.in_timed_region) time a launch beside the other context's kernels" % k_steps)
         if agg_k is not agg:
             rt = roofline_of(agg, args.precision, stride, None, contexts=args.streams)

@@ -33,6 +33,11 @@ CONVERSION = {"M": 1.0, "DM": 0.1, "CM": 0.01, "MM": 0.001, "IN": 0.0254, "FT": 
 # potential, next to a borehole wall with a kink every 0.1 m.  3D: 1.0 (the reference's field as it is).
 DEFAULT_SCALE = {2: 0.35, 3: 1.0}
 
+# Contexts (HIP stream + arena + host thread) per GPU when the caller does not say (gpu_workers = 0).  bench.py, size L, same box,
+# points/s on SURVEY 8d's span: 1 context 91-101, 2: 109.7-110.3 / 115.3-115.9, 3: 113.3-113.4 / 117.2, 4: 110.1
+# (profiles/r04_i_bench_streams*.json, r04_c_bench_streams*.json).
+DEFAULT_CONTEXTS = 3
+
 
 def lattice_mesh_key(dim, domain_radius, batch, scale, seed=0) -> tuple:
     """What a lattice mesh depends on: the electrode pattern of the batch in its own frame, size multiplier and seed - not the
@@ -241,10 +246,10 @@ class Model:
     # -- workers (remo3d.py:552-599, 887-899) ------------------------------------------------------
     def initialize_workers(self, cpu_workers=4, gpu_workers=0, context_factory: Optional[Callable] = None):
         """The reference spawns MPI workers here (remo3d.py:552-599); this build opens GPU contexts in the
-        calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (0, the default, = two), each
+        calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (0, the default, = DEFAULT_CONTEXTS), each
         with its own HIP stream and arena and driven by its own host thread in simulate_logs, so batches
-        overlap on the GPU the way the reference's GPU workers overlap (two fill the launch-latency gaps of
-        one: +15 % in 3D, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
+        overlap on the GPU the way the reference's GPU workers overlap (three fill the launch-latency gaps of
+        one: +15-25 % in 3D, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
         cpu_workers is validated like the reference and sizes the pool of mesh-generating processes (there is no CPU
         solver).  Under torchrun this is also where the rank joins the process group (sweep.init_from_env)."""
         if type(cpu_workers) != int or type(gpu_workers) != int:
@@ -263,9 +268,9 @@ class Model:
         make = context_factory or solver.Context     # context_factory(device): a stand-in solver for the CPU tests of the sweep
         self.ctx = make(device)
         # contexts on this GPU: gpu_workers of them (at most 4); the reference's default gpu_workers = 0 means "no GPU worker"
-        # there and "the build's default" here: TWO contexts - the launch-latency-bound quarter of one batch's PCG step (the chain
-        # of small launches on the vertex block) is filled by the other batch's kernels: +16 % points/s in 3D, more in 2D
-        n_ctx = 2 if gpu_workers == 0 else min(gpu_workers, 4)
+        # there and "the build's default" here: DEFAULT_CONTEXTS - the launch-latency-bound quarter of one batch's PCG step (the
+        # chain of small launches on the vertex block) is filled by the other batches' kernels
+        n_ctx = DEFAULT_CONTEXTS if gpu_workers == 0 else min(gpu_workers, 4)
         self.extra_ctx = [make(device) for _ in range(n_ctx - 1)]
 
     def shutdown_workers(self):

@@ -1,15 +1,18 @@
 #!/bin/bash
 # HBM traffic of the operator application of the bench workload: FETCH_SIZE / WRITE_SIZE / read-request-size passes (one counter
 # group per pass, kernel trace only - never with the trace domains gpurun refuses), condensed on the box by tools/pmc_traffic.py.
-# The profiled run builds its meshes in-process (no child processes behind the profiler's preloaded library), so it takes the
-# first 20 depths of the headline sweep (8 batches) instead of 100: per-launch averages, same kernels, same mesh sizes.
+# The profiled runs take the first 8 batches of the HEADLINE sweep itself (100 depths, mesh size L), one context, batches resident:
+# an un-profiled run of the same command first leaves their meshes in the on-disk cache (meshgen.cached_mesh), so the profiled
+# processes build nothing and start no child process behind the profiler's preloaded library.
 # usage (GPU box, repo root): bash tools/collect_traffic.sh OUT_JSON [bench args...]
 set -e
 OUT=$(realpath -m $1); shift
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 export REMO_BENCH_TRACE_MESH=1
-ARGS="--steps 1 --warmup 0 --depths 20 --no-cpu --no-extras --mesh-workers 1 $@"
+ARGS="--steps 1 --warmup 0 --depths 100 --batches 8 --streams 1 --resident --no-cpu --no-extras $@"
+python3 $REPO/bench.py $ARGS > /tmp/bench_plain.json 2> /tmp/plain.err || { tail -5 /tmp/plain.err; exit 1; }
+echo "un-profiled pass done (meshes cached)"
 rm -rf /tmp/pf /tmp/pw /tmp/pr
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 $REPO/bench.py $ARGS > /tmp/bench_pf.json 2> /tmp/pf.err || { tail -5 /tmp/pf.err; exit 1; }
 echo "fetch pass done"

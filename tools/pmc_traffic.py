@@ -36,7 +36,7 @@ bench = json.load(open(sys.argv[3]))
 cfg = bench["config"]
 op = cfg.get("operator", "csr")
 if op == "patch":
-    keys = [k for k in fetch if k.startswith("remo::k_patch_apply<double") and k.endswith(", 0>")] + [k for k in fetch if k.startswith("remo::k_patch_dot")]
+    keys = [k for k in fetch if k.startswith("remo::k_patch_apply<double")] + [k for k in fetch if k.startswith("remo::k_patch_dot")]
 else:
     keys = [k for k in fetch if "k_spmm" in k and ", true" in k][:1]
 parts = {}
@@ -45,8 +45,10 @@ for k in keys:
     parts[k] = dict(launches=fetch[k]["launches"], read_bytes=rd, write_bytes=write.get(k, {"avg": 0.0})["avg"] * 1024.0)
 total = sum(p["read_bytes"] + p["write_bytes"] for p in parts.values())
 size = re.search(r"mesh size (\w+)", cfg["workload"])
-out = dict(command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_{sum,32B_sum,128B_sum} --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --depths 20 --no-cpu --no-extras --mesh-workers 1 (three passes)",
+rf = bench.get("roofline", {})
+out = dict(command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_{sum,32B_sum,128B_sum} --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --depths 100 --batches 8 --streams 1 --resident --no-cpu --no-extras (three passes)",
            workload=cfg["workload"], mesh_size=size.group(1) if size else None, operator=op, mesh_T=cfg.get("mesh_T"), n_free=cfg["n_free"], nnz=cfg["nnz"],
+           algorithmic_bytes_per_launch_same_launches=rf.get("algorithmic_bytes_per_launch"), launches_timed=rf.get("launches"),
            kernels=parts, spmm=dict(traffic_bytes_per_launch=total, kernels=keys),
            correction=("read bytes = 32 n32 + 64 n64 + 128 n128 from the TCC_EA0_RDREQ size counters (FETCH_SIZE = 64 B x requests under-counts the 128-B "
                        "requests of coalesced streams, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported") if sized else

@@ -157,14 +157,17 @@ class Model:
 
     # -- model (remo3d.py:344-548) ---------------------------------------------------------------
     def set_model_parameters(self, formation_model, borehole_model, borehole_geometry_type="diameter", dip=0):
-        if isinstance(formation_model, str):
-            self.formation_model = self.load_formation_parameters(formation_model)
-        elif isinstance(formation_model, np.ndarray):
-            self.formation_model = self.set_formation_parameters(formation_model)
-        if isinstance(borehole_model, str):
-            self.borehole_model = self.load_borehole_parameters(borehole_model, borehole_geometry_type)
-        elif isinstance(borehole_model, np.ndarray):
-            self.borehole_model = self.set_borehole_parameters(borehole_model, borehole_geometry_type)
+        """Formation and borehole model from table files (paths) or from arrays in metres (remo3d.py:344-377: same argument
+        meaning; an argument of any other type is ignored there and is a TypeError here)."""
+        def model_from(source, from_file, from_array, what):
+            if isinstance(source, (str, os.PathLike)):
+                return from_file(os.fspath(source))
+            if isinstance(source, np.ndarray):
+                return from_array(source)
+            raise TypeError("{} model has to be a file name or a numpy array, not {}".format(what, type(source).__name__))
+        self.formation_model = model_from(formation_model, self.load_formation_parameters, self.set_formation_parameters, "formation")
+        self.borehole_model = model_from(borehole_model, lambda f: self.load_borehole_parameters(f, borehole_geometry_type),
+                                         lambda a: self.set_borehole_parameters(a, borehole_geometry_type), "borehole")
         self.dip_deg, self.dip_rad = self.set_dip(dip)
         self._check_model_geometry()
 

@@ -65,6 +65,10 @@ struct remo_ctx {
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> spmv_ev;
     uint64_t run_id = 0;  // the arena holds the system / solution of the batch that ran last
+    // input pool of the one-shot entry (remo_solve_batch): the mesh arrays of the batch in hand, grow-only - a sweep of thousands of
+    // batches then makes no hipMalloc / hipFree per batch (hipFree synchronises the whole device, i.e. the other contexts' streams)
+    char *in_pool = nullptr;
+    size_t in_cap = 0;
     double floor_stage[REMO_MAX_RHS] = {};   // host staging of the mixed mode's <Cr,r> floors (outlives the async copy)
 
     template <class T> T *take(size_t count) { return ar.lo<T>(count); }
@@ -103,6 +107,7 @@ struct remo_batch {
     double *d_coords = nullptr, *d_sigma = nullptr;
     int32_t *d_mat = nullptr, *d_conn = nullptr, *d_bconn = nullptr;
     uint8_t *d_bdir = nullptr;
+    bool pooled = false;     // the six arrays live in the context's input pool (remo_solve_batch): not freed with the batch
     // last system (pointers into the context arena; valid until the next run on the context)
     bool has_system = false;
     DeviceSymbolic sym;
@@ -404,6 +409,7 @@ void remo_ctx_destroy(remo_ctx_t *ctx) {
     for (auto &ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
     if (ctx->ar.base) hipFree(ctx->ar.base);
+    if (ctx->in_pool) hipFree(ctx->in_pool);
     if (ctx->d_M2) hipFree(ctx->d_M2);
     if (ctx->d_M3) hipFree(ctx->d_M3);
     if (ctx->d_M2q) hipFree(ctx->d_M2q);
@@ -415,9 +421,9 @@ void remo_ctx_destroy(remo_ctx_t *ctx) {
 
 const char *remo_last_error(remo_ctx_t *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma, int32_t n_rhs,
-                      const int32_t *src_ptr, const double *src_z, const double *src_I, const int32_t *eval_ptr,
-                      const double *eval_z, remo_batch_t **out) {
+static int batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma, int32_t n_rhs,
+                        const int32_t *src_ptr, const double *src_z, const double *src_I, const int32_t *eval_ptr,
+                        const double *eval_z, remo_batch_t **out, bool pooled) {
     if (!ctx) return REMO_ERR_ARG;
     if (!mesh || !sigma || !out || n_mat <= 0 || n_rhs <= 0 || !src_ptr || !eval_ptr)
         return fail(ctx, REMO_ERR_ARG, "null or empty argument");
@@ -448,9 +454,28 @@ int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, c
         b->src_I.assign(src_I, src_I + src_ptr[n_rhs]);
         b->eval_z.assign(eval_z, eval_z + eval_ptr[n_rhs]);
         hipStream_t s = ctx->stream;
+        b->pooled = pooled;
+        size_t pool_at = 0;
+        if (pooled) {     // one grow-only device buffer per context holds the inputs of the batch in hand
+            const size_t need = align_up(sizeof(double) * size_t(b->nv) * dim) + align_up(sizeof(int32_t) * size_t(b->nt) * nb) + align_up(sizeof(int32_t) * size_t(b->nt)) +
+                                align_up(sizeof(double) * size_t(n_mat)) + align_up(sizeof(int32_t) * size_t(b->nbf) * dim + 4) + align_up(size_t(b->nbf) + 4) + 4096;
+            if (need > ctx->in_cap) {
+                HIP_TRY(hipStreamSynchronize(s));
+                if (ctx->in_pool) HIP_TRY(hipFree(ctx->in_pool));
+                ctx->in_pool = nullptr; ctx->in_cap = 0;
+                const size_t want = align_up(need + need / 4, 4096);
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->in_pool), want));
+                ctx->in_cap = want;
+            }
+        }
         auto up = [&](auto **dst, const auto *src, size_t count) {
             using T = std::remove_const_t<std::remove_pointer_t<decltype(src)>>;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), sizeof(T) * (count ? count : 1)));
+            if (pooled) {
+                *dst = reinterpret_cast<T *>(ctx->in_pool + pool_at);
+                pool_at += align_up(sizeof(T) * (count ? count : 1));
+            } else {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), sizeof(T) * (count ? count : 1)));
+            }
             if (count) HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, s));
         };
         up(&b->d_coords, mesh->coords, size_t(b->nv) * dim);
@@ -469,9 +494,16 @@ int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, c
     }
 }
 
+int remo_batch_create(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, const double *sigma, int32_t n_rhs,
+                      const int32_t *src_ptr, const double *src_z, const double *src_I, const int32_t *eval_ptr,
+                      const double *eval_z, remo_batch_t **out) {
+    return batch_create(ctx, mesh, n_mat, sigma, n_rhs, src_ptr, src_z, src_I, eval_ptr, eval_z, out, false);
+}
+
 void remo_batch_destroy(remo_ctx_t *ctx, remo_batch_t *b) {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (!b->pooled)
     for (void *p : {(void *)b->d_coords, (void *)b->d_mat, (void *)b->d_sigma, (void *)b->d_conn, (void *)b->d_bconn, (void *)b->d_bdir})
         if (p) (void)hipFree(p);
     delete b;
@@ -916,7 +948,7 @@ int remo_solve_batch(remo_ctx_t *ctx, const remo_mesh_t *mesh, int32_t n_mat, co
     if (u_out && eval_ptr && n_rhs > 0)
         for (int i = 0; i < eval_ptr[n_rhs]; ++i) u_out[i] = std::nan("");
     remo_batch_t *b = nullptr;
-    int rc = remo_batch_create(ctx, mesh, n_mat, sigma, n_rhs, src_ptr, src_z, src_I, eval_ptr, eval_z, &b);
+    int rc = batch_create(ctx, mesh, n_mat, sigma, n_rhs, src_ptr, src_z, src_I, eval_ptr, eval_z, &b, true);     // inputs into the context's pool: no hipMalloc / hipFree per batch
     if (rc != REMO_OK) return rc;
     rc = remo_batch_run(ctx, b, opts, stats);
     if (rc >= 0 && u_out) remo_batch_fetch(ctx, b, u_out);

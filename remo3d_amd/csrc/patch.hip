@@ -485,6 +485,9 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
 //        and the stores of patch i - 1) | barrier | rows out (y or slab) - no wait on memory anywhere but that one, long satisfied.
 // <x, A x> is kept in a register across the patches of the workgroup and leaves it once, at the end.
 // R = the batch's largest row count; the image is sized by it, so two (small patches: three) workgroups share a CU's 160 KB.
+#ifndef REMO_STAMP_WAVE
+#define REMO_STAMP_WAVE 0        /* which wave of a persistent workgroup reports its phase clocks (probe builds) */
+#endif
 typedef const void __attribute__((address_space(1))) *dma_src_t;
 typedef void __attribute__((address_space(3))) *dma_dst_t;
 
@@ -735,9 +738,6 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
         slot3 = s1;
     }
     if constexpr (STAMP) {
-#ifndef REMO_STAMP_WAVE
-#define REMO_STAMP_WAVE 0        /* which wave of the workgroup reports (the waves queue behind each other in the output phase) */
-#endif
         if (tid == 64 * REMO_STAMP_WAVE) {
             for (int k = 0; k < 10; ++k) stamps[int64_t(blockIdx.x) * 12 + k] = ph[k];
             stamps[int64_t(blockIdx.x) * 12 + 10] = p1 - p0;
@@ -754,6 +754,282 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
             else ppart[int64_t(p0) * K + tid] = pick<K>(dot, tid);
         }
         if (!pbins)      // one row of sums per PATCH is what the folding launches read: this workgroup's other patches contribute zero
+            for (int64_t j = tid; j < int64_t(p1 - p0 - 1) * K; j += BLK) ppart[int64_t(p0 + 1) * K + j] = 0.0;
+    }
+}
+
+// ---- apply, persistent form with the prefetch through REGISTERS ----------------------------------------------------------------
+// Same idea as k_patch_apply_p - a workgroup walks a run of patches and fetches patch i + 1 while it computes patch i - with
+// what the LDS-DMA version taught: the DMA instructions cost a wave ~240 ticks each to issue (25 per patch) and the second row
+// image halves the workgroups per CU.  Here the next patch's x rows are ordinary buffer loads into registers (one value per lane and
+// pass, up to 12 in flight: 24 VGPRs in fp64), issued before the tensor chains and written into the ONE row image once the
+// current patch's results have been read out of it; row tables travel the same way one patch further ahead, the element's local
+// rows and metric terms are requested behind the chains (their registers are free then) for the next turn.  LDS: one image + two
+// slots of tables (~32 KB: the register budget - three waves per SIMD - decides the residency, not LDS).  Barriers wait for LDS
+// only (lds_barrier): a wave never waits for memory except where the compiler counts the loads it needs next.
+inline size_t patch_lds_bytes_r(int R, int K, int E) {
+    const size_t Rp = size_t((R + 255) & ~255);
+    return size_t(R + 2) * size_t(K) * 8 + 4 * Rp * 4 + size_t(E) * 88 + 64;
+}
+
+template <class T, int K, bool STAMP = false>
+__global__ void __launch_bounds__(256, 3) k_patch_apply_r(PatchTables tb, int R, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+                                                          double *__restrict__ ppart, const double *__restrict__ scal, int step, double *__restrict__ pbins,
+                                                          long long *__restrict__ stamps) {
+    if (scal && solve_done(scal, step)) return;
+    long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tk = 0;
+#define REMO_PH(k) if constexpr (STAMP) { const long long now_ = __builtin_readcyclecounter(); ph[k] += now_ - tk; tk = now_; }
+    constexpr int BLK = 256, EK = BLK / K, U = kPatchPasses, TJ = 4;     // TJ table words per lane: up to 1024 rows
+    constexpr uint32_t S = sizeof(T);
+    extern __shared__ double lds_raw[];
+    __shared__ double smem[16 * K];
+    const int tid = threadIdx.x;
+    const int Rp = (R + 255) & ~255;
+    const int E = tb.E;
+    double *const ya = lds_raw;                                          // [(R + 2)][K] fp64 accumulators; the same bytes hold the x image (T) before
+    T *const xs = reinterpret_cast<T *>(lds_raw);
+    int32_t *const trow0 = reinterpret_cast<int32_t *>(lds_raw + size_t(R + 2) * K);   // [2][Rp]
+    int32_t *const tout0 = trow0 + 2 * Rp;                                              // [2][Rp]
+    double *const ecm = reinterpret_cast<double *>(tout0 + 2 * Rp);                    // [E][6] metric terms of the current patch's elements
+    uint32_t *const eli = reinterpret_cast<uint32_t *>(ecm + size_t(E) * 6);           // [E][10] their local rows, two per word
+    const int64_t per = (tb.npatch + 7) >> 3;
+    const int64_t xb = int64_t(blockIdx.x & 7) * per, xe = (xb + per < tb.npatch) ? xb + per : tb.npatch;
+    const int64_t cnt = xe > xb ? xe - xb : 0;
+    const int64_t nwx = int64_t(gridDim.x >> 3), w = int64_t(blockIdx.x >> 3);
+    const int64_t share = cnt / nwx, extra = cnt % nwx;
+    const int64_t p0_ = xb + w * share + (w < extra ? w : extra);
+    const int p0 = __builtin_amdgcn_readfirstlane(int(p0_)), p1 = __builtin_amdgcn_readfirstlane(int(p0_ + share + (w < extra ? 1 : 0)));
+    if (p0 >= p1) return;                                 // (the whole workgroup)
+    typedef const int32_t __attribute__((address_space(4))) *cint_t;
+    const cint_t pcnt = (cint_t)tb.pcount;
+    auto clampR = [&](int c) { return c < R ? c : R; };
+
+    const int el = tid / K, c0 = tid - el * K;
+    const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);
+    const int Rr = tb.spread > 1 ? tb.spread : 1;
+    const int run = el % Rr, rbase = E / Rr, rextra = E % Rr;
+    const int elp = Rr > 1 ? (run * rbase + (run < rextra ? run : rextra) + el / Rr) : el;
+    const bool has_el = el < E;
+    const rsrc_t rx = make_rsrc(x, uint64_t(tb.n) * K * S);
+    const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
+    const rsrc_t rpr = make_rsrc(tb.prow, uint64_t(tb.npatch) * uint64_t(tb.rows_cap) * 4), rpo = make_rsrc(tb.pout, uint64_t(tb.npatch) * uint64_t(tb.rows_cap) * 4);
+
+    // this lane's table words of patch p (rows tid + 256 j): range-checked buffer loads, nothing beyond the patch's rows is requested
+    auto load_tables = [&](int p, int rows, int32_t (&tr)[TJ], int32_t (&to)[TJ]) {
+        const uint32_t base = uint32_t(p) * uint32_t(tb.rows_cap);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = tid + 256 * j;
+            const uint32_t off = m < rows ? (base + uint32_t(m)) * 4u : kOutOfRange;
+            tr[j] = int32_t(__builtin_amdgcn_raw_buffer_load_b32(rpr, off, 0, 0));
+            to[j] = int32_t(__builtin_amdgcn_raw_buffer_load_b32(rpo, off, 0, 0));
+        }
+    };
+    auto store_tables = [&](int slot, int rows, const int32_t (&tr)[TJ], const int32_t (&to)[TJ]) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = tid + 256 * j;
+            if (m < rows) { trow0[slot * Rp + m] = tr[j]; tout0[slot * Rp + m] = to[j]; }
+        }
+    };
+    // x values of the patch whose row numbers are in table slot `slot`: pass u = row el + EK u, this lane's column
+    auto load_x = [&](int slot, int rows, T (&xr)[U]) {
+        const int32_t *const tr = trow0 + slot * Rp;
+        int el_l = el;
+        asm volatile("" : "+v"(el_l));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = el_l + EK * u;
+            int32_t r = -1;
+            if (u * EK < rows) r = (m < rows ? tr[m] : -1) | off_mask;
+            T v[1];
+            buf_load<T, 1>(rx, r >= 0 ? __umul24(uint32_t(r), K * S) + uint32_t(c0) * S : kOutOfRange, v);
+            xr[u] = v[0];
+        }
+    };
+    auto store_x = [&](int rows, const T (&xr)[U]) {
+        int el_s = el;
+        asm volatile("" : "+v"(el_s));                   // (no loop-invariant addresses held across the patch loop: see the read-out of the results)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = el_s + EK * u;
+            if (m < rows && off_mask == 0) xs[m * K + c0] = xr[u];
+        }
+    };
+    // local rows and metric terms of this lane's element of patch p into registers (lanes of an element ask for the same words)
+    auto load_elem = [&](int p, uint32_t (&li)[10], double (&cm)[6]) {
+        const int64_t e = int64_t(p) * E + elp;
+        const bool active = has_el && e < tb.nt;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) li[q] = 0u;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cm[q] = 0.0;
+        if (active) {
+            const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);
+#pragma unroll
+            for (int q = 0; q < 10; ++q) li[q] = pl[q];
+            const double *ce = tb.C + e * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cm[q] = ce[q];
+        }
+    };
+    // ... and from registers into the workgroup's LDS copy (the k lanes of an element write the same words): they are wanted three
+    // times per patch - x values, metric contraction, accumulation - and would otherwise sit in 22 registers through the tensor chains
+    auto park_elem = [&](const uint32_t (&li)[10], const double (&cm)[6]) {
+        if (has_el && c0 == 0) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) eli[elp * 10 + q] = li[q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ecm[elp * 6 + q] = cm[q];
+        }
+    };
+
+    int rows_cur = clampR(pcnt[p0]);
+    int rows_nxt = (p0 + 1 < p1) ? clampR(pcnt[p0 + 1]) : 0;
+    // in flight across the loop's back edge: the NEXT patch's element data and row tables (requested behind the tensor chains)
+    uint32_t li_n[10];
+    double cm_n[6];
+    int32_t tr_n[TJ], to_n[TJ];
+    {   // prologue: the first patch's tables, rows and element data (the only exposed round trips), the second patch's tables on their way
+        int32_t tr[TJ], to[TJ];
+        load_tables(p0, rows_cur, tr, to);
+        load_elem(p0, li_n, cm_n);
+        load_tables(p0 + 1 < p1 ? p0 + 1 : p0, rows_nxt, tr_n, to_n);
+        store_tables(0, rows_cur, tr, to);
+        __syncthreads();
+        T xr[U];
+        load_x(0, rows_cur, xr);
+        store_x(rows_cur, xr);
+    }
+    double d0 = 0.0;
+    for (int p = p0; p < p1; ++p) {
+        const int it = p - p0, sc = it & 1, sn = sc ^ 1;
+        const int32_t *const trow_c = trow0 + sc * Rp, *const tout_c = tout0 + sc * Rp;
+        const int rows_nn = (p + 2 < p1) ? clampR(pcnt[p + 2]) : 0;
+        if constexpr (STAMP) tk = __builtin_readcyclecounter();
+        if (tid < K) xs[R * K + tid] = T(0);              // the row constrained dofs read
+        park_elem(li_n, cm_n);                           // element data of patch p (requested a patch ago)
+        store_tables(sn, rows_nxt, tr_n, to_n);          // tables of patch p + 1 into the slot patch p - 1 has left
+        lds_barrier();                                   // B0: the image holds X(p), slot sc the tables of p, slot sn those of p + 1
+        REMO_PH(0)
+        const int64_t e = int64_t(p) * E + elp;
+        const bool active = has_el && e < tb.nt;
+        const uint32_t *const my_li = eli + (has_el ? elp : 0) * 10;
+        const double *const my_cm = ecm + (has_el ? elp : 0) * 6;
+        T xv[20];
+        {
+            uint32_t li[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) li[q] = my_li[q];
+#define REMO_PATCH_L(i) ((li[(i) >> 1] >> (16 * ((i) & 1))) & 0xFFFFu)
+#pragma unroll
+            for (int i = 0; i < 20; ++i) xv[i] = xs[REMO_PATCH_L(i) * K + c0];
+        }
+        REMO_PH(2)
+        lds_barrier();                                   // B1: every lane holds its x values: the image becomes the accumulators
+        REMO_PH(3)
+        for (int j = tid; j < rows_cur * K; j += BLK) ya[j] = 0.0;
+        if (tid < K) ya[R * K + tid] = 0.0;
+        lds_barrier();                                   // B2
+        REMO_PH(4)
+        typedef const T __attribute__((address_space(4))) *ctab_t;
+        T g[30];
+#pragma unroll
+        for (int j = 0; j < 30; ++j) g[j] = T(0);
+        if (active) {
+            ctab_t tgrad = (ctab_t)ElemTables<T>::grad();
+            if constexpr (sizeof(T) == 8) asm volatile("" : "+s"(tgrad));
+            REMO_ELEM_GRAD(T, xv, g, tgrad)
+        }
+        // patch p + 1's x values are requested HERE, between the two tensor chains: the twenty x values of this patch are dead, the
+        // thirty gradients alive - the point of lowest register pressure that still leaves the loads half the arithmetic phase, two
+        // barriers and the read-out of the results to arrive (nothing is requested behind the run's last patch: rows_nxt = 0)
+#pragma unroll
+        for (int j = 0; j < 30; ++j) asm volatile("" : "+v"(g[j]));      // (the first chain is complete here, not sunk behind the loads)
+        T xr[U];
+        load_x(sn, rows_nxt, xr);
+        REMO_PH(1)
+        if (active) {
+            T yv[20];
+            ctab_t tdiv = (ctab_t)ElemTables<T>::div();
+            if constexpr (sizeof(T) == 8) asm volatile("" : "+s"(tdiv));
+            {
+                const T c11 = T(my_cm[0]), c12 = T(my_cm[1]), c13 = T(my_cm[2]), c22 = T(my_cm[3]), c23 = T(my_cm[4]), c33 = T(my_cm[5]);
+                T dd = T(0);
+#pragma unroll
+                for (int m = 0; m < 10; ++m) {     // h = c~ g, in place; g . h on the way
+                    const T g1 = g[m], g2 = g[10 + m], g3 = g[20 + m];
+                    const T h1 = c11 * g1 + c12 * g2 + c13 * g3, h2 = c12 * g1 + c22 * g2 + c23 * g3, h3 = c13 * g1 + c23 * g2 + c33 * g3;
+                    dd += g1 * h1 + g2 * h2 + g3 * h3;
+                    g[m] = h1; g[10 + m] = h2; g[20 + m] = h3;
+                }
+                d0 += double(dd);
+            }
+            REMO_ELEM_DIV(T, g, yv, tdiv)
+            uint32_t li[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) li[q] = my_li[q];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) lds_add(ya + REMO_PATCH_L(i) * K + c0, double(yv[i]));
+#undef REMO_PATCH_L
+        }
+        REMO_PH(5)
+        // the next patch's element data and the row tables of the one after it: requested here, behind the chains (their registers
+        // are free now), parked in LDS at the top of the next turn
+        load_elem(p + 1 < p1 ? p + 1 : p, li_n, cm_n);
+        load_tables(p + 2 < p1 ? p + 2 : p, rows_nn, tr_n, to_n);
+        lds_barrier();                                   // B3: accumulators complete
+        REMO_PH(6)
+        // results of patch p out of LDS into registers (the image is about to receive patch p + 1), stored after that
+        int32_t orow[U], oslot[U];
+        T ov[U];
+        const int npass = (rows_cur + EK - 1) / EK;
+        // (the LDS addresses of the passes are loop invariants; hoisted out of the patch loop they would sit in a dozen registers through
+        // the tensor chains - i.e. in scratch, and a scratch reload waits for every load still in flight: formed anew from an opaque copy)
+        int el_o = el;
+        asm volatile("" : "+v"(el_o));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            orow[u] = -1; oslot[u] = -1; ov[u] = T(0);
+            if (u < npass) {
+                const int m = el_o + EK * u;
+                const bool in = m < rows_cur;
+                orow[u] = (in ? trow_c[m] : -1) | off_mask; oslot[u] = in ? tout_c[m] : -1;
+                ov[u] = T(ya[(in ? m : 0) * K + c0]);
+            }
+        }
+        lds_barrier();                                   // B4: every lane has its results: the image is free
+        REMO_PH(7)
+        store_x(rows_nxt, xr);                           // X(p + 1) (the compiler waits for exactly these loads: what was requested after them stays in flight)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < npass) {                             // one of the two stores of a value is out of range: dropped by the hardware, no branch
+                const bool have = orow[u] >= 0;
+                T v[1] = {ov[u]};
+                buf_store<T, 1>(ry, (have && oslot[u] < 0) ? __umul24(uint32_t(orow[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v);
+                buf_store<T, 1>(rb, (have && oslot[u] >= 0) ? __umul24(uint32_t(oslot[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v);
+            }
+        }
+        REMO_PH(8)
+        rows_cur = rows_nxt; rows_nxt = rows_nn;
+    }
+    if constexpr (STAMP) {
+        if (tid == 64 * REMO_STAMP_WAVE) {
+            for (int k = 0; k < 10; ++k) stamps[int64_t(blockIdx.x) * 12 + k] = ph[k];
+            stamps[int64_t(blockIdx.x) * 12 + 10] = p1 - p0;
+        }
+    }
+#undef REMO_PH
+    if (ppart) {
+        double dot[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
+        block_sum<K>(dot, smem);
+        if (tid < K) {
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[int64_t(p0) * K + tid] = pick<K>(dot, tid);
+        }
+        if (!pbins)
             for (int64_t j = tid; j < int64_t(p1 - p0 - 1) * K; j += BLK) ppart[int64_t(p0 + 1) * K + j] = 0.0;
     }
 }
@@ -841,7 +1117,7 @@ void set_patch_lean(int v) { g_patch_lean = v; }
 // two forms give the same points/s (115.9 against 115.3).  Kept for that record and as the starting point of a version with
 // 16-byte-tiled rows; not the default.
 int g_patch_persist = 0;
-void set_patch_persist(int v) { g_patch_persist = v ? 1 : 0; }
+void set_patch_persist(int v) { g_patch_persist = (v == 1 || v == 2) ? v : 0; }
 int g_patch_wgs_per_xcd = 0;   // key 35: workgroups per XCD of the persistent kernel (0 = as many as stay resident); tests make small meshes walk several patches per workgroup
 void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
 int g_patch_trim = 1;
@@ -924,7 +1200,26 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
-    if (g_patch_persist && tb.block == 256 && (g_patch_mode == 0 || g_patch_mode == 4)) {
+    if (g_patch_persist == 2 && tb.block == 256 && (g_patch_mode == 0 || g_patch_mode == 4) && P.lds_rows <= kPatchPasses * (256 / K) && P.lds_rows <= 1024) {
+        // persistent form with the prefetch through registers: three workgroups per CU by its registers (LDS would allow four or five)
+        const size_t bytes = patch_lds_bytes_r(P.lds_rows, K, tb.E);
+        int wpc = int((160 * 1024) / (bytes + 16 * K * 8 + 1024));
+        if (wpc > 3) wpc = 3;
+        if (wpc >= 1 && bytes <= 64 * 1024 - 2048) {
+            int64_t nwx = int64_t(32) * wpc;
+            if (g_patch_wgs_per_xcd > 0 && g_patch_wgs_per_xcd < nwx) nwx = g_patch_wgs_per_xcd;
+            if (nwx > per) nwx = per;
+            if (nwx < 1) nwx = 1;
+#ifdef REMO_PROBES
+            if (g_patch_stamps && K == 5)
+                hipLaunchKernelGGL((k_patch_apply_r<T, K, true>), dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins, g_patch_stamps);
+            else
+#endif
+            hipLaunchKernelGGL((k_patch_apply_r<T, K>), dim3(int(nwx * 8)), dim3(256), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, bins, (long long *)nullptr);
+            launched = true;
+        }
+    }
+    if (!launched && g_patch_persist == 1 && tb.block == 256 && (g_patch_mode == 0 || g_patch_mode == 4)) {
         // persistent form: as many workgroups as stay resident (LDS: two row images + tables per workgroup), 32 CUs per XCD
         const size_t bytes = patch_lds_bytes_p(P.lds_rows, K, tb.E);
         const size_t lds_cu = 160 * 1024, per_wg = bytes + 16 * K * 8 + 1024;

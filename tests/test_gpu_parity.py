@@ -614,8 +614,8 @@ def test_patch_operator_is_the_assembled_matrix(k, mesh3d, gpu_ctx):
 @pytest.mark.parametrize("k", [1, 3, 5, 8])
 def test_persistent_patch_kernel_is_the_same_operator(k, mesh3d, gpu_ctx):
     """The patch operator's two launch forms - one workgroup per patch (the default) and persistent workgroups that walk a run of
-    patches while the next patch's rows, tables and element data arrive by LDS-DMA (remo_debug_tune key 34 = 1; round 4: measured
-    slower in isolation, level under two contexts, kept as an option) - are the same operator: products agree with each other, with the CSR product and with the oracle's to rounding, also when a workgroup walks
+    patches while the next patch's rows, tables and element data arrive - by LDS-DMA (remo_debug_tune key 34 = 1) or through registers
+    (key 34 = 2) - are the same operator: products agree with each other, with the CSR product and with the oracle's to rounding, also when a workgroup walks
     MANY patches (key 35: few workgroups per XCD; the small test mesh would otherwise give every workgroup one patch and never
     reach the prefetch) or exactly one or two, in fp64 and through a mixed-precision solve."""
     from remo3d_amd import _lib, solver
@@ -631,21 +631,20 @@ def test_persistent_patch_kernel_is_the_same_operator(k, mesh3d, gpu_ctx):
     try:
         assert b.run(solver.make_opts(preconditioner="local", rtol=1e-2, op="patch")) == 0 and b.stats["op_used"] == 3
         ys = {}
-        for persist, wgs in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 7)):
+        for persist, wgs in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 7), (2, 0), (2, 1), (2, 2), (2, 3), (2, 7)):
             L.remo_debug_tune(34, persist); L.remo_debug_tune(35, wgs)
             ys[(persist, wgs)], _ = b.spmv(xx, reps=3)
             assert np.max(np.abs(ys[(persist, wgs)] - yr)) <= 5e-12 * scale, (persist, wgs)
-        for wgs in (1, 3):        # whole solves, the rows shared by patches summed by the update launch, <p, A p> added by the workgroups
-            L.remo_debug_tune(34, 1); L.remo_debug_tune(35, wgs)
+        for form, wgs in ((1, 1), (1, 3), (2, 1), (2, 3), (2, 0)):   # whole solves, the rows shared by patches summed by the update launch, <p, A p> added by the workgroups
             for precision in ("fp64", "mixed"):
+                L.remo_debug_tune(34, form); L.remo_debug_tune(35, wgs)
                 assert b.run(solver.make_opts(rtol=1e-11, op="patch", precision=precision, maxsteps=5000)) == 0
                 u1 = np.concatenate(b.fetch())
                 assert np.max(b.true_relres()) < 5e-11
                 L.remo_debug_tune(34, 0)
                 assert b.run(solver.make_opts(rtol=1e-11, op="patch", precision=precision, maxsteps=5000)) == 0
                 u0 = np.concatenate(b.fetch())
-                L.remo_debug_tune(34, 1)
-                assert np.allclose(u1, u0, rtol=1e-8 if precision == "fp64" else 3e-7, atol=0), (wgs, precision)
+                assert np.allclose(u1, u0, rtol=1e-8 if precision == "fp64" else 3e-7, atol=0), (form, wgs, precision)
     finally:
         L.remo_debug_tune(34, 0); L.remo_debug_tune(35, 0)
         b.close()

@@ -20,15 +20,18 @@ def main():
         b = ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"])
         b.run(solver.make_opts(rtol=1e-8))
         print("T=%d n=%d op_used=%d" % (w["mesh"].n_elems, b.stats["n_free"], b.stats["op_used"]), flush=True)
+        names_r = ["park+B0", "chain 1 + issue of next x", "x->regs", "B1", "clear+B2", "chain 2 + accumulate", "issue element/table loads + B3", "read-out + B4", "store X(p+1) + rows out", "-"]
         for fp32 in (0, 1):
+          for mode in (2, 1):
             for nw in wgs:
-                L.remo_debug_tune(34, 1); L.remo_debug_tune(35, nw)
+                L.remo_debug_tune(34, mode); L.remo_debug_tune(35, nw)
                 ph = (C.c_double * 16)()
                 rc = L.remo_debug_patch_phases_p(ctx._h, b._h, fp32, ph)
                 if rc != 0:
                     print("remo_debug_patch_phases_p:", ctx.last_error()); return
                 tot = sum(ph[i] for i in range(10))
-                print("%s wgs/xcd %s: per patch (ticks) " % ("fp32" if fp32 else "fp64", nw or "auto") + "  ".join("%s %.0f" % (nm, ph[i]) for i, nm in enumerate(names[:10]))
+                nm_ = names_r if mode == 2 else names
+                print("%s %s wgs/xcd %s: per patch (ticks) " % ("fp32" if fp32 else "fp64", "REGISTER prefetch" if mode == 2 else "LDS-DMA prefetch", nw or "auto") + "  ".join("%s %.0f" % (nm, ph[i]) for i, nm in enumerate(nm_[:10]))
                       + "  | sum %.0f  patches %d  workgroups %d  busiest workgroup %.0f ticks  application %.1f us" % (tot, ph[10], ph[11], ph[12], ph[13]), flush=True)
             L.remo_debug_tune(34, 0)
             ph = (C.c_double * 16)()

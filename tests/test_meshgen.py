@@ -153,3 +153,62 @@ def test_conforming_3d_mesh_with_caliper_and_several_flushed_zones():
     rad = np.sqrt((m.coords ** 2).sum(1))
     assert np.allclose(rad[m.bconn[m.bdirichlet == 1]], R, rtol=0, atol=1e-9) and rad.max() <= R * (1 + 1e-12)
     assert meshgen.interface_straddlers(m, fg, bh, dip) <= 5e-3 * m.n_elems
+
+
+def test_mesh_cache_on_disk(tmp_path, monkeypatch):
+    """meshgen.cached_mesh: a mesh is built once per key and directory, read back identical (arrays and meta), rebuilt for another
+    key, shared between processes through the file's lock (two processes asking for the same new key build it once), and
+    REMO_MESH_CACHE=0 switches the cache off."""
+    import multiprocessing
+    from remo3d_amd import meshgen
+    monkeypatch.setenv("REMO_MESH_CACHE", str(tmp_path))
+    calls = []
+
+    def build():
+        calls.append(1)
+        return meshgen.make_mesh(3, 50.0, [0.0, 0.1], scale=12.0, seed=0)
+    a = meshgen.cached_mesh(("t", 1), build)
+    b = meshgen.cached_mesh(("t", 1), build)
+    assert len(calls) == 1
+    for name in ("coords", "conn", "mat", "bconn", "bdirichlet"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)) and getattr(a, name).dtype == getattr(b, name).dtype
+    assert b.dim == 3 and b.meta["sources_z"] == a.meta["sources_z"] and np.array_equal(b.meta["node_h"], a.meta["node_h"])
+    meshgen.cached_mesh(("t", 2), build)
+    assert len(calls) == 2
+    ctx = multiprocessing.get_context("spawn")
+    with ctx.Pool(2) as pool:
+        res = pool.map(_cache_worker, [str(tmp_path)] * 2)
+    assert sorted(r[0] for r in res) == [0, 1], res          # exactly one of the two built it
+    assert res[0][1] == res[1][1]
+    monkeypatch.setenv("REMO_MESH_CACHE", "0")
+    meshgen.cached_mesh(("t", 1), build)
+    assert len(calls) == 3
+
+
+def _cache_worker(directory):
+    import os
+    os.environ["REMO_MESH_CACHE"] = directory
+    from remo3d_amd import meshgen
+    built = []
+
+    def build():
+        import time
+        built.append(1)
+        time.sleep(1.0)               # the other process arrives while this one builds: it must wait on the lock, not build too
+        return meshgen.make_mesh(2, 50.0, [0.0], scale=6.0, seed=1)
+    m = meshgen.cached_mesh(("worker", 7), build)
+    return len(built), int(m.n_elems)
+
+
+def test_lattice_mesh_key_groups_the_batches_of_a_sweep():
+    """The bench's 100-depth sweep (40 batches) needs six distinct lattice meshes: the key depends on the electrode pattern of a batch
+    in its own frame, not on the depth; bench.build_workload sends the first batch of every pattern to the mesh pool first."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from remo3d_amd.model import lattice_mesh_key
+    m, depths, sim, batches, mud, bg = bench._model_and_batches(100)
+    keys = [lattice_mesh_key(3, 50.0, b, 1.2, 0) for b in batches]
+    assert len(batches) == 40 and len(set(keys)) == 6
+    assert all(isinstance(v, (int, float, tuple)) for v in keys[0])      # hashable, plain: goes into a file name through repr()
+    assert lattice_mesh_key(3, 50.0, batches[0], 1.2, 0) != lattice_mesh_key(3, 50.0, batches[0], 2.5, 0)

@@ -559,6 +559,14 @@ def log(msg):
 T_START = time.time()
 
 
+def _tuned(d, forced="auto"):
+    """Model's per-mesh choice for conforming meshes as keywords of main()'s make_opts (`coarse` travels as coarse_solver)."""
+    d = dict(d)
+    c = d.pop("coarse", "auto")
+    d["coarse_solver"] = forced if forced != "auto" else c
+    return d
+
+
 def size_scale(size):
     """'S' / 'M' / 'L' / 'XL' or a number = the multiplier on the reference's size field itself."""
     return SIZES[size] if size in SIZES else float(size)
@@ -715,6 +723,7 @@ def main():
     stride = max(1, args.event_stride)
 
     def make_opts(time_kernels=True, precision=args.precision, op=args.op, coarse="auto", streams=args.streams, **kw):
+        coarse = kw.pop("coarse_solver", coarse)
         if args.coarse:
             kw.setdefault("coarse_degree", int(args.coarse.split(",")[0])); kw.setdefault("coarse_ratio", int(args.coarse.split(",")[1]))
         return solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,
@@ -726,7 +735,7 @@ def main():
     per_batch = None
     if args.mesh == "conforming":
         from remo3d_amd.model import tuned_coarse_for_conforming
-        per_batch = [make_opts(**tuned_coarse_for_conforming(w["mesh"].n_nodes)) for w in work]
+        per_batch = [make_opts(**_tuned(tuned_coarse_for_conforming(w["mesh"].n_nodes))) for w in work]
     runner = Runner(work, n_depths, local, opts, streams=args.streams, schedule=args.schedule, all_resident=dynamic, resident=args.resident,
                     per_batch_opts=per_batch)
     h2d = not args.resident and not dynamic
@@ -823,7 +832,7 @@ def main():
         pb2 = None
         if name.startswith("conforming-"):
             from remo3d_amd.model import tuned_coarse_for_conforming
-            pb2 = [make_opts(precision=prec2, op=op2, coarse=coarse2, streams=nctx2, **tuned_coarse_for_conforming(w["mesh"].n_nodes)) for w in w2["work"]]
+            pb2 = [make_opts(precision=prec2, op=op2, streams=nctx2, **_tuned(tuned_coarse_for_conforming(w["mesh"].n_nodes), coarse2)) for w in w2["work"]]
         r2 = Runner(w2["work"], len(w2["depths"]), local, make_opts(precision=prec2, op=op2, coarse=coarse2, streams=nctx2), streams=nctx2, per_batch_opts=pb2)
         st2 = 2
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)

@@ -515,6 +515,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
     remo_opts_t o;
     if (opts_in) o = *opts_in; else remo_opts_default(&o);
     if (o.maxsteps <= 0 || !(o.rtol > 0.0)) return fail(ctx, REMO_ERR_ARG, "maxsteps and rtol must be positive");
+    if (o.coarse < 0 || o.coarse > 3) return fail(ctx, REMO_ERR_ARG, "remo_opts_t.coarse must be 0 (by dimension), 1 (polynomial), 2 (multigrid cycle) or 3 (cycle, else polynomial)");
     if (o.op != 0 && o.op != 2 && o.op != 3)
         return fail(ctx, REMO_ERR_ARG, "remo_opts_t.op must be 0 (default), 2 (CSR product) or 3 (patch operator); 1, the round-2 element-wise operator, left the library with ABI 7");
     remo_stats_t local;
@@ -565,7 +566,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)
         need += size_t(nv + 64) * kEllWidth * 12 + size_t(nv + 64) * 8;        // its fixed-width image
         need += size_t(nv + 64) * (4 * 4 * size_t(kmax) + 8);                    // fp32 Chebyshev chain of the fp64 solve
-        const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || (o.coarse == 0 && dim == 2 && o.coarse_degree <= 0));   // an explicit degree asks for the polynomial
+        const bool want_amg = o.preconditioner != 0 && g_amg != 1 && (g_amg == 2 || o.coarse == 2 || o.coarse == 3 || (o.coarse == 0 && dim == 2 && o.coarse_degree <= 0));   // coarse = 0: an explicit degree asks for the polynomial
         if (want_amg) need += size_t(nv + 64) * (dim == 2 ? 1536 : 3072) * 2 + (1 << 20);   // multigrid hierarchy of the vertex block + its scratch
         if (o.precision == 1)   // fp32 copies of the matrix values and of every PCG vector
             need += size_t(nv + 64) * 200 * 8;

@@ -48,11 +48,14 @@ def lattice_mesh_key(dim, domain_radius, batch, scale, seed=0) -> tuple:
 
 
 def tuned_coarse_for_conforming(n_nodes: int) -> dict:
-    """Chebyshev degree / interval of the P1 block for the revolved conforming 3D meshes: graded and sheared, they want a higher
-    degree and a wider interval than the library's default for isotropic meshes of the same vertex count (GPU scan,
-    tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)."""
+    """Solver of the P1 block for the revolved conforming 3D meshes.  Graded and sheared, they want more of it than isotropic meshes
+    of the same vertex count: one multigrid cycle where its hierarchy can be built (GPU scan at 64 k vertices, tools/scan_conforming.py,
+    profiles/r04_p_scan_conforming_vertex_solver.log: 62.4 ms of solve per batch and 187 steps against 69.5 ms / 198 steps with the best
+    polynomial; Model end to end 63 against 54 points/s), else a Chebyshev polynomial of higher degree on a wider interval than the
+    library's default (tools/scan_coarse3d.py: 8 / 300 at 19 k vertices, 14 / 400 at 51 k)."""
     rel = max(int(n_nodes), 1) / 12600.0
-    return dict(coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))), coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
+    return dict(coarse="amg_or_chebyshev", coarse_degree=int(min(16, max(6, round(7.0 * rel ** 0.5)))),
+                coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
 
 
 def default_mesh_provider(scale: Optional[float] = None, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
@@ -334,7 +337,7 @@ class Model:
         base_kw.update(extra)
         opts = solver.make_opts(**base_kw)
         tuned_coarse = (mesh_provider is None and base_kw["preconditioner"] == "multigrid"
-                        and "coarse_degree" not in extra and "coarse_ratio" not in extra)     # the default 3D provider = conforming revolved meshes
+                        and not any(k in extra for k in ("coarse", "coarse_degree", "coarse_ratio")))     # the default 3D provider = conforming revolved meshes
 
         n_tools = len(self.tools)
         results = np.zeros((len(measurement_depths), n_tools))

@@ -51,9 +51,9 @@ def make_opts(preconditioner="multigrid", condense=True, maxsteps=1000, rtol=1e-
     if op not in ("auto", "csr", "patch"):
         raise ValueError("op must be 'auto' (patch operator in 3D, CSR product in 2D), 'csr' (SpMM on the assembled matrix) or 'patch' (matrix-free, 3D)")
     o.op = {"auto": 0, "csr": 2, "patch": 3}[op]
-    if coarse not in ("auto", "chebyshev", "amg"):
-        raise ValueError("coarse must be 'auto' (multigrid cycle in 2D, Chebyshev polynomial in 3D), 'chebyshev' or 'amg'")
-    o.coarse = {"auto": 0, "chebyshev": 1, "amg": 2}[coarse]   # solver of the P1 block inside "multigrid"
+    if coarse not in ("auto", "chebyshev", "amg", "amg_or_chebyshev"):
+        raise ValueError("coarse must be 'auto' (multigrid cycle in 2D, Chebyshev polynomial in 3D), 'chebyshev', 'amg' or 'amg_or_chebyshev' (the cycle if its hierarchy can be built)")
+    o.coarse = {"auto": 0, "chebyshev": 1, "amg": 2, "amg_or_chebyshev": 3}[coarse]   # solver of the P1 block inside "multigrid"
     if quadrature not in ("exact", "degree4"):
         raise ValueError("quadrature must be 'exact' or 'degree4' (2D reference tensors by the 6-point rule)")
     o.quadrature = 1 if quadrature == "degree4" else 0

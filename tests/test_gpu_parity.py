@@ -815,12 +815,13 @@ def test_fp32_chebyshev_chain_inside_the_fp64_solve(mesh3d, gpu_ctx):
 def test_multigrid_cycle_on_the_vertex_block(which, precision, mesh2d, mesh3d, gpu_ctx):
     """remo_opts_t.coarse: the smoothed-aggregation V(1,1) cycle (amg.hip) and the Chebyshev polynomial are two solvers of the
     same P1 block inside the same two-level preconditioner: potentials agree with the oracle to 1e-8 either way, the run reports
-    which one it used, the default is the cycle in 2D and the polynomial in 3D, and an explicit degree selects the polynomial."""
+    which one it used, the default is the cycle in 2D and the polynomial in 3D, an explicit degree selects the polynomial under
+    "auto", and "amg_or_chebyshev" takes the cycle wherever its hierarchy can be built."""
     from remo3d_amd import solver
     mesh = mesh2d if which == "2d" else mesh3d
     o, ref = _oracle_solve(mesh, SIGMA3, True)
     steps = {}
-    for coarse, used in (("chebyshev", 1), ("amg", 2), ("auto", 2 if which == "2d" else 1)):
+    for coarse, used in (("chebyshev", 1), ("amg", 2), ("auto", 2 if which == "2d" else 1), ("amg_or_chebyshev", 2)):
         outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-12, maxsteps=20000, precision=precision, coarse=coarse))
         assert rc == 0 and st["coarse_used"] == used
         steps[coarse] = max(st["iterations"][:3])
@@ -831,6 +832,13 @@ def test_multigrid_cycle_on_the_vertex_block(which, precision, mesh2d, mesh3d, g
     assert rc == 0 and st["coarse_used"] == 1
     outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(preconditioner="local", rtol=1e-10, maxsteps=20000, coarse="amg"))
     assert rc == 0 and st["coarse_used"] == 0
+    # "amg_or_chebyshev" (what Model asks for on its conforming 3D meshes) with an explicit degree: still the cycle where it can be built
+    outs, st, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, solver.make_opts(rtol=1e-10, coarse="amg_or_chebyshev", coarse_degree=8, coarse_ratio=100))
+    assert rc == 0 and st["coarse_used"] == 2
+    o_bad = solver.make_opts(rtol=1e-10)
+    o_bad.coarse = 7
+    _, _, rc = gpu_ctx.solve_batch(mesh, SIGMA3, SRC, EVAL, o_bad, raise_on_error=False)
+    assert rc == solver.REMO_ERR_ARG
 
 
 @pytest.mark.gpu

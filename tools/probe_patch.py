@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Operator application (k = 5) and whole solves through the three operators on bench meshes:
-   python tools/probe_patch.py S M L      (CSR product | element-wise | patch, two / one column per lane)"""
+"""Operator application (k = 5) and whole solves through the two operators on bench meshes, ablations and phase clocks of the patch kernel
+(needs the probes build: make -C remo3d_amd/csrc probes; REMO_LIB=remo3d_amd/libremo3d_hip_probes.so):
+   python tools/probe_patch.py S M L      (CSR product | patch)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +44,7 @@ def main():
             w = work[sz]
             b = ctx.batch(w["mesh"], w["sigma"], w["sources"], w["evals"])
             ref = None
-            for name, op, cpl, mode in (("csr", "csr", 1, 0), ("element", "element", 1, 0), ("patch", "patch", 1, 0),
+            for name, op, cpl, mode in (("csr", "csr", 1, 0), ("patch", "patch", 1, 0),
                                         ("patch/no-atomics", "patch", 1, 1), ("patch/no-arithmetic", "patch", 1, 2), ("patch/no-output", "patch", 1, 3)):
                 if only and name not in only:
                     continue

@@ -617,6 +617,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline leg (no kernel-timing leg, sizes, end-to-end or CPU legs)")
     ap.add_argument("--mesh-workers", type=int, default=10, help="CPU processes that build the synthetic meshes side by side (before any GPU work)")
     ap.add_argument("--coarse", default="", metavar="DEGREE,RATIO", help="experiments only: Chebyshev degree and interval ratio of the P1 block (default: by vertex count)")
+    ap.add_argument("--vertex-solver", default="auto", choices=["auto", "chebyshev", "amg", "amg_or_chebyshev"],
+                    help="experiments only: solver of the P1 block inside the two-level preconditioner (auto = the library's default: polynomial in 3D)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B experiments only (library built with -DREMO_PROBES): remo_debug_tune(KEY, VALUE) before the run (include/remo3d_hip_debug.h lists the keys)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket SpMV launches with HIP events")
@@ -640,7 +642,7 @@ def main():
     dynamic = args.schedule == "dynamic" and world > 1
     profiled = under_profiler()
     extras = ((world == 1) and not args.no_extras and not args.resident and args.precision == "fp64" and args.mesh == "lattice" and not args.tune
-              and args.op == "auto" and not args.coarse and not args.batches and not profiled)
+              and args.op == "auto" and not args.coarse and args.vertex_solver == "auto" and not args.batches and not profiled)
     extra_specs = []
     if extras and args.sizes:
         for spec in args.sizes.split(","):
@@ -724,6 +726,8 @@ def main():
 
     def make_opts(time_kernels=True, precision=args.precision, op=args.op, coarse="auto", streams=args.streams, **kw):
         coarse = kw.pop("coarse_solver", coarse)
+        if coarse == "auto" and args.vertex_solver != "auto":
+            coarse = args.vertex_solver
         if args.coarse:
             kw.setdefault("coarse_degree", int(args.coarse.split(",")[0])); kw.setdefault("coarse_ratio", int(args.coarse.split(",")[1]))
         return solver.make_opts(preconditioner="multigrid", condense=True, rtol=args.rtol, maxsteps=args.maxsteps,

@@ -736,10 +736,16 @@ def main():
     opts = make_opts()
     work = wl["work"]
     n_depths = len(wl["depths"])
-    per_batch = None
-    if args.mesh == "conforming":
-        from remo3d_amd.model import tuned_coarse_for_conforming
-        per_batch = [make_opts(**_tuned(tuned_coarse_for_conforming(w["mesh"].n_nodes))) for w in work]
+    # the solver of the P1 block is the one `Model` would ask for on these meshes with this many contexts (model.vertex_solver_options):
+    # interface-conforming meshes - the multigrid cycle with the tuned polynomial behind it; lattice meshes - the cycle when several contexts
+    # share the GPU (the headline), the library's default polynomial on one context (the kernel-timing leg and the `sizes` legs)
+    from remo3d_amd.model import vertex_solver_options
+
+    def per_batch_opts(batches, n_ctx, conforming, **kw):
+        if args.vertex_solver != "auto" or args.coarse:
+            return None
+        return [make_opts(streams=n_ctx, **kw, **_tuned(vertex_solver_options(w["mesh"].dim, w["mesh"].n_nodes, conforming, n_ctx))) for w in batches]
+    per_batch = per_batch_opts(work, args.streams, args.mesh == "conforming")
     runner = Runner(work, n_depths, local, opts, streams=args.streams, schedule=args.schedule, all_resident=dynamic, resident=args.resident,
                     per_batch_opts=per_batch)
     h2d = not args.resident and not dynamic
@@ -778,7 +784,9 @@ def main():
                            batches_total=wl["n_batches"], batches_rank0=int(agg["batches"]), rhs_rank0=sum(len(w["sources"]) for w in work) if not dynamic else None,
                            points_total=n_points, mesh_T=int(work[0]["mesh"].n_elems), n_free=int(agg.get("n0", agg["n"])), nnz=int(agg["nnz"]), rtol=args.rtol,
                            maxsteps=args.maxsteps, precision=args.precision, operator={0: "csr", 3: "patch"}.get(int(agg["op_used"]), "csr"),
-                           preconditioner="multigrid = Chebyshev polynomial on the P1 vertex block (degree / interval by vertex count: 5 on lmax/90..lmax at 12.6 k vertices, 12 on lmax/320 at 83 k) + Jacobi on edge/face dofs",
+                           preconditioner="multigrid = solver of the P1 vertex block + Jacobi on edge/face dofs; block solver as Model chooses it (model.vertex_solver_options): one smoothed-aggregation multigrid cycle when several contexts share the GPU, "
+                                          "else a Chebyshev polynomial (degree / interval by vertex count: 12 on lmax/320 at 83 k vertices)",
+                           vertex_block_solver={0: "none", 1: "chebyshev", 2: "multigrid cycle"}[int(agg.get("coarse_used", 1))],
                            max_pcg_iterations=int(agg["max_it"]), pcg_steps_per_batch=agg["pcg_steps"] / max(1, agg["batches"]),
                            batches_not_converged=int(agg["not_converged"]), nan_points=int(np.isnan(slab).sum()),
                            distinct_meshes=wl.get("distinct_meshes"), mesh_generation_excluded_s=wl["mesh_s"], all_mesh_generation_wall_s=mesh_wall),
@@ -795,7 +803,7 @@ def main():
         if args.streams == 1 and args.resident:
             agg_k, dt_k, slab_k, k_steps = agg, dt, slab, args.steps            # the headline leg already is that leg
         else:
-            r1 = Runner(work, n_depths, local, make_opts(streams=1), streams=1, per_batch_opts=per_batch)
+            r1 = Runner(work, n_depths, local, make_opts(streams=1), streams=1, per_batch_opts=per_batch_opts(work, 1, args.mesh == "conforming"))
             k_steps = max(1, min(args.steps, 2))
             dt_k, slab_k, agg_k, _ = timed(r1, k_steps, 1, sync)
             first_outs = first_outs or dict(r1.first_outs)
@@ -831,12 +839,11 @@ def main():
     for name, w2 in extra_wl:
         prec2 = "mixed" if "/mixed" in name else args.precision
         op2 = "csr" if "/csr" in name else ("patch" if "/patch" in name else args.op)
-        coarse2 = "chebyshev" if "/chebyshev" in name else "auto"
+        coarse2 = "chebyshev" if "/chebyshev" in name else ("amg_or_chebyshev" if "/amg" in name else "auto")
         nctx2 = 2 if "/2ctx" in name else 1
         pb2 = None
-        if name.startswith("conforming-"):
-            from remo3d_amd.model import tuned_coarse_for_conforming
-            pb2 = [make_opts(precision=prec2, op=op2, streams=nctx2, **_tuned(tuned_coarse_for_conforming(w["mesh"].n_nodes), coarse2)) for w in w2["work"]]
+        if not name.startswith("2D"):
+            pb2 = [make_opts(precision=prec2, op=op2, streams=nctx2, **_tuned(vertex_solver_options(3, w["mesh"].n_nodes, name.startswith("conforming-"), nctx2), coarse2)) for w in w2["work"]]
         r2 = Runner(w2["work"], len(w2["depths"]), local, make_opts(precision=prec2, op=op2, coarse=coarse2, streams=nctx2), streams=nctx2, per_batch_opts=pb2)
         st2 = 2
         dt2, slab2, agg2, _ = timed(r2, st2, 1, sync)

@@ -58,6 +58,21 @@ def tuned_coarse_for_conforming(n_nodes: int) -> dict:
                 coarse_ratio=int(min(1200, max(150, round(220.0 * rel ** (2.0 / 3.0))))))
 
 
+def vertex_solver_options(dim: int, n_nodes: int, conforming: bool, n_contexts: int) -> dict:
+    """The solver of the P1 block `Model` asks for when the caller did not choose one (keywords of solver.make_opts).
+    2D: the library's default (one multigrid cycle).  3D, interface-conforming meshes of the default provider: the cycle with the tuned
+    polynomial behind it (tuned_coarse_for_conforming).  3D, any other mesh: the cycle (polynomial if its hierarchy cannot be built)
+    WHEN SEVERAL CONTEXTS SHARE THE GPU - its set-up waits for the host once per level and its twelve launches per step are latency,
+    which other batches' kernels fill: bench.py on three contexts, points/s with the cycle against the polynomial: size S 434 / 410,
+    M 253 / 222, L 131 / 122, L mixed 187 / 177 (profiles/r04_s_*, r04_u_*); on ONE context the polynomial (the library's default in 3D)
+    is ahead: L 93 / 87, S 252 / 205 (profiles/r04_t_*)."""
+    if dim != 3:
+        return {}
+    if conforming:
+        return tuned_coarse_for_conforming(n_nodes)
+    return dict(coarse="amg_or_chebyshev") if n_contexts >= 2 else {}
+
+
 def default_mesh_provider(scale: Optional[float] = None, seed: int = 0, mesh_3d: str = "conforming", sectors: int = 6) -> Callable:
     """Batch mesh factory.  scale: multiplier on the reference's size field (None: DEFAULT_SCALE by dimension).  2D: interface-conforming half-disc meshes built per batch.
     3D, mesh_3d = "conforming" (default): the 2D conforming mesh of the window revolved in the sheared
@@ -336,8 +351,9 @@ class Model:
         base_kw = dict(preconditioner=preconditioner, condense=condense, rtol=rtol, maxsteps=maxsteps, precision=precision)
         base_kw.update(extra)
         opts = solver.make_opts(**base_kw)
-        tuned_coarse = (mesh_provider is None and base_kw["preconditioner"] == "multigrid"
-                        and not any(k in extra for k in ("coarse", "coarse_degree", "coarse_ratio")))     # the default 3D provider = conforming revolved meshes
+        # the solver of the P1 block follows the mesh kind and the number of contexts (vertex_solver_options) unless the caller chose one
+        tuned_coarse = base_kw["preconditioner"] == "multigrid" and not any(k in extra for k in ("coarse", "coarse_degree", "coarse_ratio"))
+        conforming_default = mesh_provider is None     # the default 3D provider = conforming revolved meshes
 
         n_tools = len(self.tools)
         results = np.zeros((len(measurement_depths), n_tools))
@@ -388,6 +404,7 @@ class Model:
                 for attr, v in hidden.items():
                     setattr(main_mod, attr, v)
         ctxs = [self.ctx] + list(getattr(self, "extra_ctx", []))
+        n_ctx_total = len(ctxs)
         free_ctx = queue.Queue()
         for c in ctxs:
             free_ctx.put(c)
@@ -435,8 +452,10 @@ class Model:
                 sources, evals, readers = tasks.batch_rhs(batch, self.tools)
                 t1 = time.time()
                 bopts = opts
-                if tuned_coarse and mesh.dim == 3:
-                    bopts = solver.make_opts(**dict(base_kw, **tuned_coarse_for_conforming(mesh.n_nodes)))
+                if tuned_coarse and getattr(mesh, "dim", 0) == 3:
+                    vs = vertex_solver_options(3, mesh.n_nodes, conforming_default, n_ctx_total)
+                    if vs:
+                        bopts = solver.make_opts(**dict(base_kw, **vs))
                 c = free_ctx.get()
                 try:
                     outs, st, rc = c.solve_batch(mesh, sigma, sources, evals, bopts)

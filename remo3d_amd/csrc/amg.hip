@@ -345,16 +345,20 @@ __global__ void __launch_bounds__(256) k_tr_fill(int64_t n, const int32_t *__res
         rv[at] = val[p];
     }
 }
-constexpr int kTrMax = 512;   // longest row of R the LDS sort takes
-__global__ void __launch_bounds__(256) k_tr_sort(int64_t nr, const int32_t *__restrict__ rrp, int32_t *__restrict__ rc, double *__restrict__ rv, int32_t *flag) {
-    __shared__ int32_t keys[4][kTrMax];
-    __shared__ double vals[4][kTrMax];
+// Rows of R longer than MINLEN and up to MAXLEN entries, WAVES rows per workgroup (a wave sorts its row in LDS).  Two launches cover a
+// level: <0, 512, 4> takes nearly every row; <512, 4096, 1> the few long ones (at 184 k vertices of a graded lattice mesh a coarse
+// aggregate's smoothed prolongator column holds more than 512 entries: the hierarchy could not be built) - beyond 4096 flag 4.
+constexpr int kTrMax = 512, kTrMaxLong = 4096;
+template <int MINLEN, int MAXLEN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_tr_sort(int64_t nr, const int32_t *__restrict__ rrp, int32_t *__restrict__ rc, double *__restrict__ rv, int32_t *flag) {
+    __shared__ int32_t keys[WAVES][MAXLEN];
+    __shared__ double vals[WAVES][MAXLEN];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    const int64_t row = int64_t(blockIdx.x) * WAVES + wave;
     if (row >= nr) return;
     const int32_t rs = rrp[row], len = rrp[row + 1] - rs;
-    if (len <= 1) return;
-    if (len > kTrMax) { if (lane == 0) atomicOr(flag, 4); return; }
+    if (len <= 1 || len <= MINLEN) return;
+    if (len > MAXLEN) { if (lane == 0 && MAXLEN == kTrMaxLong) atomicOr(flag, 4); return; }
     int32_t *K = keys[wave];
     double *V = vals[wave];
     int m = 64;
@@ -793,7 +797,8 @@ int amg_build(Arena &ar, hipStream_t s, int hs, int64_t nv, const int32_t *rowpt
             hipLaunchKernelGGL(k_tr_count, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, tcnt);
             scan_counts(ar, s, nc, tcnt, R.rowptr);
             hipLaunchKernelGGL(k_tr_fill, dim3(g), dim3(256), 0, s, n, P.rowptr, P.col, P.val, R.rowptr, cursor, R.col, R.val);
-            hipLaunchKernelGGL(k_tr_sort, dim3(grid_rows(nc, 4)), dim3(256), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
+            hipLaunchKernelGGL((k_tr_sort<0, kTrMax, 4>), dim3(grid_rows(nc, 4)), dim3(256), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
+            hipLaunchKernelGGL((k_tr_sort<kTrMax, kTrMaxLong, 1>), dim3(grid_rows(nc, 1)), dim3(64), 0, s, nc, R.rowptr, R.col, R.val, d_flag);
         }
         lv.r_rowptr = R.rowptr; lv.r_col = R.col; lv.r_val = R.val;
         // ---- A' = R (A P): A P in scratch with room for (4 << room) nnz(A) entries, A' at most as many entries as A ----

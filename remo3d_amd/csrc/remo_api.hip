@@ -152,6 +152,7 @@ int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves abov
 int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
 int g_dot_bins = 1;   // key 28: 1 = the patches add their <p, A p> straight into the update launch's rows (default), 0 = a row per patch + k_patch_dot
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
+int g_extra_apply = 0; // key 36 (probe builds): extra operator applications (apply + shared-row sums, results discarded) per PCG step: what a step with more applications would cost
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
@@ -195,6 +196,10 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
         } else {
             launch_spmm(A, k, (const T *)buf.p, buf.q, buf.part_pq, (const double *)buf.rz0, buf.nb_spmv, s, step, buf.defer_q);
         }
+#ifdef REMO_PROBES
+        for (int extra = 0; extra < g_extra_apply; ++extra)      // (idempotent: the same q and slab again, no dot products)
+            launch_spmm(A, k, (const T *)buf.p, buf.q, (double *)nullptr, (const double *)buf.rz0, buf.nb_spmv, s, step, false);
+#endif
         bool replaced = false;
         if constexpr (std::is_same<T, float>::value) {
             if (hooks && replace_next) {
@@ -1506,6 +1511,7 @@ int remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 28) g_dot_bins = value;
     else if (key == 32) set_patch_spread(value);
     else if (key == 33) set_patch_trim(value);
+    else if (key == 36) g_extra_apply = value;
     else set_spmm_tuning(key, value);
     return 0;
 #else

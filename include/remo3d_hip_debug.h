@@ -58,9 +58,7 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  *   17  0 = the multigrid cycle of an fp64 solve stays in fp64 (default: fp32 storage);
  *   18  0 = elements taken in the caller's order (default 1: sorted by their two smallest vertices);
  *   22  0 = rows shared by patches summed by k_patch_reduce instead of the PCG's update launch;
- *   24  0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image;
- *   34  1 = patch operator as persistent workgroups that prefetch the next patch by LDS-DMA (round 4: parity-green, 138 us against 112 at size L: not the default) instead of one workgroup per patch (0);
- *   35  workgroups per XCD of the persistent patch kernel (0 = as many as stay resident): small test meshes walk several patches per workgroup.
+ *   24  0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image.
  *
  * (b) ONLY IN A LIBRARY BUILT WITH -DREMO_PROBES (`make -C remo3d_amd/csrc probes` -> libremo3d_hip_probes.so, loaded by the tools
  * through REMO_LIB=...): rejected experiments and ablations, some of which give WRONG RESULTS ON PURPOSE.  The product ignores them:
@@ -69,7 +67,10 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  *    mode of the patch kernel (1 no LDS atomics, 2 no arithmetic, 3 no output); 23: 1 = boundary slab row-major; 26 register-lean order
  *    of the patch kernel (0 never, 1 always; product: fp32 storage only); 27: 0 = slab slots of a shared row fetched one by one;
  *    28: 0 = a row of <p, A p> per patch + a folding launch; 32 runs of the patch's list per wave (product: 4); 33: 0 = every
- *    workgroup walks the largest patch's row count.  remo_debug_patch_phases and remo_debug_grid_barrier also need that build. */
+ *    workgroup walks the largest patch's row count; 34: 1 / 2 = the patch operator as persistent workgroups that prefetch the next patch by
+ *    LDS-DMA / through registers (round 4: parity-green, 138 / 111.5 us against 112 at size L: DESIGN.md section 8), 35 their number per XCD
+ *    (0 = as many as stay resident); 36 extra operator applications per PCG step (results discarded: what more applications would cost).
+ *    remo_debug_patch_phases[_p] and remo_debug_grid_barrier also need that build. */
 int remo_debug_tune(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
 #undef REMO_PASSES
 }
 
+#ifdef REMO_PROBES     // the two persistent forms of the kernel: measured, parity-green, not faster: tools/ builds only
 // ---- apply, persistent form --------------------------------------------------------------------------------------------------
 // The kernel above is a chain of dependent memory round trips per workgroup: row tables, then x rows, then arithmetic, then stores;
 // four workgroups per CU overlap each other's waits only partly (a workgroup spent 11 k of its 27 k cycles waiting for the two trips).
@@ -1034,6 +1035,8 @@ __global__ void __launch_bounds__(256, 3) k_patch_apply_r(PatchTables tb, int R,
     }
 }
 
+#endif   // REMO_PROBES
+
 // Rows shared by several patches: sum of the row's slab slots in ascending patch order.  DOT: the patches' <x, A x> are folded
 // into <= 1024 partial rows for the consumer (every workgroup takes a fixed subset: deterministic given the patches' sums).
 template <class T, int K, bool DOT>
@@ -1200,6 +1203,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;
+#ifdef REMO_PROBES
     if (g_patch_persist == 2 && tb.block == 256 && (g_patch_mode == 0 || g_patch_mode == 4) && P.lds_rows <= kPatchPasses * (256 / K) && P.lds_rows <= 1024) {
         // persistent form with the prefetch through registers: three workgroups per CU by its registers (LDS would allow four or five)
         const size_t bytes = patch_lds_bytes_r(P.lds_rows, K, tb.E);
@@ -1247,6 +1251,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
             }
         }
     }
+#endif
 #ifdef REMO_PROBES      // ablations (wrong results on purpose), the phase probe and 512-thread workgroups: tools/ builds only (make probes)
     if constexpr (K == 5) {     // ablations and the phase probe (tools/probe_patch.py)
         if (!launched && g_patch_mode >= 1 && g_patch_mode <= 3 + (g_patch_stamps ? 1 : 0)) {

@@ -1495,8 +1495,6 @@ int remo_debug_tune(int32_t key, int32_t value) {
         case 18: set_element_order(value); return 0;    // elements in the caller's order
         case 22: g_defer_q = value; return 0;           // shared rows summed by k_patch_reduce / by the update launch
         case 24: g_ell = value; return 0;               // fixed-width image of the vertex block
-        case 34: set_patch_persist(value); return 0;    // patch operator: persistent workgroups (default) / one workgroup per patch
-        case 35: set_patch_wgs_per_xcd(value); return 0; // ... their number per XCD (0 = as many as stay resident)
         default: break;
     }
 #ifdef REMO_PROBES
@@ -1511,6 +1509,8 @@ int remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 28) g_dot_bins = value;
     else if (key == 32) set_patch_spread(value);
     else if (key == 33) set_patch_trim(value);
+    else if (key == 34) set_patch_persist(value);
+    else if (key == 35) set_patch_wgs_per_xcd(value);
     else if (key == 36) g_extra_apply = value;
     else set_spmm_tuning(key, value);
     return 0;

@@ -621,6 +621,9 @@ def test_persistent_patch_kernel_is_the_same_operator(k, mesh3d, gpu_ctx):
     from remo3d_amd import _lib, solver
     from oracle.fem_oracle import Oracle
     L = _lib.load()
+    if L.remo_debug_tune(34, 0) != 0:
+        pytest.skip("the persistent forms are rejected experiments: they live in the -DREMO_PROBES build only (make -C remo3d_amd/csrc probes; "
+                    "REMO_LIB=remo3d_amd/libremo3d_hip_probes.so); this run loaded the product library - record of them passing: profiles/r04_m_*")
     o = Oracle(mesh3d, SIGMA3, condense=True)
     src, ev = _rhs_block(k)
     b = gpu_ctx.batch(mesh3d, SIGMA3, src, ev)

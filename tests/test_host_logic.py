@@ -204,3 +204,22 @@ def test_mesh_workers_deliver_the_same_meshes_as_inline_generation():
         seen[workers] = m.ctx.seen
         assert not np.isnan(m.logs["A0.4M6.0N"][:, 1]).any()
     assert len(seen[0]) == 3 and seen[0] == seen[2]
+
+
+def test_vertex_solver_rule_of_the_model():
+    """model.vertex_solver_options: what `Model` asks of the library for the P1 block when the caller did not choose - 2D: nothing (the
+    library's default, the multigrid cycle); 3D on its own conforming meshes: the cycle with the tuned polynomial behind it, whatever the
+    number of contexts; 3D on other meshes: the cycle (with fallback) only when several contexts share the GPU.  The keywords are
+    make_opts keywords."""
+    from remo3d_amd import model, solver
+    assert model.DEFAULT_CONTEXTS >= 2
+    assert model.vertex_solver_options(2, 80000, False, 3) == {}
+    assert model.vertex_solver_options(3, 83000, False, 1) == {}
+    assert model.vertex_solver_options(3, 83000, False, 3) == dict(coarse="amg_or_chebyshev")
+    for n_ctx in (1, 3):
+        o = model.vertex_solver_options(3, 64000, True, n_ctx)
+        assert o["coarse"] == "amg_or_chebyshev" and 6 <= o["coarse_degree"] <= 16 and 150 <= o["coarse_ratio"] <= 1200
+        opts = solver.make_opts(**o)
+        assert opts.coarse == 3 and opts.coarse_degree == o["coarse_degree"]
+    with pytest.raises(ValueError):
+        solver.make_opts(coarse="ilu")

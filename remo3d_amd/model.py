@@ -64,7 +64,7 @@ def vertex_solver_options(dim: int, n_nodes: int, conforming: bool, n_contexts: 
     polynomial behind it (tuned_coarse_for_conforming).  3D, any other mesh: the cycle (polynomial if its hierarchy cannot be built)
     WHEN SEVERAL CONTEXTS SHARE THE GPU - its set-up waits for the host once per level and its twelve launches per step are latency,
     which other batches' kernels fill: bench.py on three contexts, points/s with the cycle against the polynomial: size S 434 / 410,
-    M 253 / 222, L 131 / 122, L mixed 187 / 177 (profiles/r04_s_*, r04_u_*); on ONE context the polynomial (the library's default in 3D)
+    M 253 / 222, L 131 / 122, L mixed 187 / 177, XL 37.0 / 33.9, XL mixed 54.6 / 49.3 (profiles/r04_s_*, r04_u_*, r04_x_*, r04_y_*); on ONE context the polynomial (the library's default in 3D)
     is ahead: L 93 / 87, S 252 / 205 (profiles/r04_t_*)."""
     if dim != 3:
         return {}

@@ -144,6 +144,7 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
 template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step, bool defer);   // patch.hip
 template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
+void set_patch_all_slab(int on);   // remo_debug_tune key 37
 void set_patch_persist(int on);   // remo_debug_tune key 34 (patch.hip k_patch_apply_p)
 void set_patch_wgs_per_xcd(int n);   // key 35
 void set_patch_block(int threads);   // 256 (default) or 512

@@ -42,7 +42,7 @@ constexpr uint64_t kNoRow = uint64_t(0x7FFFFFFF);      // constrained dof: sorts
 // bcnt[r] = number of patches that touch row r if there are at least two (the row gets that many slots in the boundary slab),
 // else 0.  The adjacency of a row lists its elements in ascending order, so its patches ascend too.
 __global__ void __launch_bounds__(256) k_patch_row_slots(int64_t n, int E, const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
-                                                         int32_t *__restrict__ bcnt) {
+                                                         int32_t *__restrict__ bcnt, int all_rows) {
     const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (r > n) return;
     int cnt = 0;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_patch_row_slots(int64_t n, int E, const
             last = p;
         }
     }
-    bcnt[r] = cnt >= 2 ? cnt : 0;
+    bcnt[r] = cnt >= (all_rows ? 1 : 2) ? cnt : 0;     // all_rows: every row goes through the slab, also the rows of one patch alone (g_patch_all_slab)
 }
 
 // One workgroup per patch: sort the patch's (row, element dof slot) pairs in LDS, number the distinct rows 0 .. M - 1 in
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_patch_row_slots(int64_t n, int E, const
 __global__ void __launch_bounds__(256) k_patch_build(int64_t nt, int E, int rows_cap, int npad, const int32_t *__restrict__ eldof,
                                                      const int32_t *__restrict__ adjptr, const uint32_t *__restrict__ adj,
                                                      uint16_t *__restrict__ lidx, int32_t *__restrict__ pcount, int32_t *__restrict__ pbcnt,
-                                                     int32_t *__restrict__ prow, int32_t *__restrict__ pout, int32_t *flag, int32_t *max_rows) {
+                                                     int32_t *__restrict__ prow, int32_t *__restrict__ pout, int32_t *flag, int32_t *max_rows, int all_rows) {
     extern __shared__ uint64_t keys[];   // [npad]
     __shared__ int32_t cnts[256];
     const int tid = threadIdx.x;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_patch_build(int64_t nt, int E, int rows
             int run = 1;
             while (j + run < nslots && row_at(j + run) == r) ++run;
             const int32_t row = int32_t(r);
-            const bool is_shared = run != adjptr[row + 1] - adjptr[row];
+            const bool is_shared = all_rows != 0 || run != adjptr[row + 1] - adjptr[row];
             prow[p * rows_cap + id] = row;
             pout[p * rows_cap + id] = is_shared ? 0 : -1;     // k_patch_slots numbers the shared rows
             shared += is_shared ? 1 : 0;
@@ -1123,6 +1123,10 @@ int g_patch_persist = 0;
 void set_patch_persist(int v) { g_patch_persist = (v == 1 || v == 2) ? v : 0; }
 int g_patch_wgs_per_xcd = 0;   // key 35: workgroups per XCD of the persistent kernel (0 = as many as stay resident); tests make small meshes walk several patches per workgroup
 void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
+// remo_debug_tune key 37 (probe builds): 1 = EVERY row of a patch goes to the patch's contiguous block of the slab, also the rows no other patch
+// touches (whole-line writes: the operator's 181 MB of writes for 125 MB of rows come from partial lines at the ends of row runs in y)
+int g_patch_all_slab = 0;
+void set_patch_all_slab(int v) { g_patch_all_slab = v ? 1 : 0; }
 int g_patch_trim = 1;
 void set_patch_trim(int v) { g_patch_trim = v; }
 int g_patch_spread = 4;
@@ -1173,9 +1177,9 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     (void)hipMemsetAsync(flag_and_max, 0, 3 * sizeof(int32_t), s);
     (void)hipMemsetAsync(prow, 0xFF, sizeof(int32_t) * (size_t(out.npatch) * rows_cap + 1), s);   // -1 behind a patch's last row
     (void)hipMemsetAsync(pbcnt + out.npatch, 0, sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt);
+    hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt, g_patch_all_slab);
     hipLaunchKernelGGL(k_patch_build, dim3(int(out.npatch)), dim3(256), size_t(npad) * 8, s, nt, E, rows_cap, npad, sy.eldof, sy.adjptr, sy.adj,
-                       lidx, pcount, pbcnt, prow, pout, flag_and_max, flag_and_max + 1);
+                       lidx, pcount, pbcnt, prow, pout, flag_and_max, flag_and_max + 1, g_patch_all_slab);
     size_t tb1 = 0, tb2 = 0;
     (void)rocprim::exclusive_scan(nullptr, tb1, bcnt, bptr, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s);
     (void)rocprim::exclusive_scan(nullptr, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);

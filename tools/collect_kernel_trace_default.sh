@@ -11,4 +11,4 @@ rm -rf /tmp/ktd
 ARGS="--no-extras --steps 1 --warmup 1 $@"
 python3 $REPO/bench.py $ARGS > /tmp/bench_plain.json 2> /tmp/plain.err || { tail -5 /tmp/plain.err; exit 1; }
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -- python3 $REPO/bench.py $ARGS > ${REPO}/${OUT}_bench_under_rocprof.json 2> /tmp/ktd.err || { tail -5 /tmp/ktd.err; exit 1; }
-python3 $REPO/tools/ktrace_stats.py /tmp/ktd ${REPO}/${OUT}_kernel_stats_working.csv | head -40 | tee ${REPO}/${OUT}_kernel_stats_working.txt
+python3 $REPO/tools/ktrace_stats.py /tmp/ktd ${REPO}/${OUT}_kernel_stats_working.csv > ${REPO}/${OUT}_kernel_stats_working.txt; head -30 ${REPO}/${OUT}_kernel_stats_working.txt

@@ -82,6 +82,10 @@ struct PatchTables {
     const int32_t *pcount = nullptr;   // [npatch] distinct free rows of the patch
     const int32_t *prow = nullptr;     // [npatch][rows_cap] matrix row of local row m, ascending
     const int32_t *pout = nullptr;     // [npatch][rows_cap] -1: the row belongs to this patch alone (result goes to y); else its slot in the boundary slab
+    const int32_t *pboff = nullptr;    // [npatch + 1] first slab slot of every patch (its rows' slots are consecutive, in ascending row order)
+    int all_slab = 1;                  // 1 (default): EVERY row of a patch goes to the patch's block of the slab, also the rows no other patch touches
+                                       //   (pout[p][m] = pboff[p] + m: the kernel stores one contiguous block and y is written by whoever sums the slab);
+                                       //   0 (remo_debug_tune key 37, probe builds): only the rows shared by several patches
     const int32_t *bptr = nullptr;     // [n + 1] entries [bptr[r], bptr[r + 1]) of bslot belong to row r, one per patch that touches it (none: not shared)
     const int32_t *bslot = nullptr;    // slab slot of each (row, patch) pair; the slab itself is patch-major (a patch's shared rows are one block)
     const double *C = nullptr;         // [nt][6] metric terms (launch_metric_terms)
@@ -144,7 +148,7 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
 template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step, bool defer);   // patch.hip
 template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
-void set_patch_all_slab(int on);   // remo_debug_tune key 37
+void set_patch_all_slab(int on);   // remo_debug_tune key 37 (probe builds): 0 = only the shared rows go through the slab (the form of rounds 3-4)
 void set_patch_persist(int on);   // remo_debug_tune key 34 (patch.hip k_patch_apply_p)
 void set_patch_wgs_per_xcd(int n);   // key 35
 void set_patch_block(int threads);   // 256 (default) or 512

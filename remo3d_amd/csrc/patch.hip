@@ -228,6 +228,13 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // is a compile-time constant of the code that runs (a switch over 1 .. U: guards inside one unrolled loop keep the loads from
     // going out together and cost what the shorter walk saves); remo_debug_tune key 33 = 0: the largest patch's count for all
     const int rows_own = tb.pcount[p];
+    // every row of the patch goes to its block of the slab (PatchTables::all_slab; the product has no other form): no slot table
+#ifdef REMO_PROBES
+    const bool lin = tb.all_slab != 0;
+#else
+    constexpr bool lin = true;
+#endif
+    const int64_t slab0 = lin ? int64_t(tb.pboff[p]) : 0;
     const int rows_p = (tb.trim && rows_own < rows) ? rows_own : rows;
     const int npass = (rows_p + EK - 1) / EK;
     const int el = tid / NL, c0 = tid - el * NL;
@@ -271,13 +278,13 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
         for (int u = 0; u < 4; ++u) {
             const int m = m0 + BLK * u;
             r[u] = m < rows ? prow[m] : -1;
-            o[u] = m < rows ? pout[m] : -1;
+            o[u] = (!lin && m < rows) ? pout[m] : -1;
         }
         if (m0 == tid) element_data();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int m = m0 + BLK * u;
-            if (m < rows_pad) { trow[m] = r[u]; tout[m] = o[u]; }
+            if (m < rows_pad) { trow[m] = r[u]; if (!lin) tout[m] = o[u]; }
         }
     }
     __syncthreads();
@@ -431,8 +438,24 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
 #undef REMO_PATCH_L
     __syncthreads();
     REMO_STAMP(5)
-    // 3. rows of this patch alone -> y; shared rows -> the patch's block of the boundary slab; one value per lane and pass again
-    if constexpr (MODE != 3) {
+    // 3. the accumulators -> the patch's block of the slab, one linear copy: value j of the image to value j of the block.  The block has
+    // its own buffer descriptor (64-bit base, the patch's rows as its range): small offsets, no limit on the slab's size, and the
+    // hardware drops what lies behind the patch's last row
+    if (MODE != 3 && lin) {
+        const rsrc_t rp = make_rsrc(Yb + slab0 * K, uint64_t(rows_own) * K * S);
+        auto put = [&](auto np_c, int m0) {
+            constexpr int NP = decltype(np_c)::value;
+            T v[NP][1];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) v[u][0] = T(ya[(m0 + el + EK * u) * K + c0]);    // (behind the staged rows: whatever LDS holds, never stored)
+#pragma unroll
+            for (int u = 0; u < NP; ++u)
+                buf_store<T, 1>(rp, off_mask == 0 ? uint32_t((m0 + el + EK * u) * K + c0) * S : kOutOfRange, v[u]);
+        };
+        REMO_PASSES(put)
+    }
+    // (probe builds, PatchTables::all_slab = 0: rows of this patch alone -> y; shared rows -> the patch's block of the slab)
+    if (MODE != 3 && !lin) {
         const rsrc_t ry = make_rsrc(y, uint64_t(tb.n) * K * S), rb = make_rsrc(Yb, uint64_t(tb.nslot_cap) * K * S);
         auto put = [&](auto np_c, int m0) {
             constexpr int NP = decltype(np_c)::value;
@@ -1123,9 +1146,12 @@ int g_patch_persist = 0;
 void set_patch_persist(int v) { g_patch_persist = (v == 1 || v == 2) ? v : 0; }
 int g_patch_wgs_per_xcd = 0;   // key 35: workgroups per XCD of the persistent kernel (0 = as many as stay resident); tests make small meshes walk several patches per workgroup
 void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
-// remo_debug_tune key 37 (probe builds): 1 = EVERY row of a patch goes to the patch's contiguous block of the slab, also the rows no other patch
-// touches (whole-line writes: the operator's 181 MB of writes for 125 MB of rows come from partial lines at the ends of row runs in y)
-int g_patch_all_slab = 0;
+// EVERY row of a patch goes to the patch's contiguous block of the slab, also the rows no other patch touches: the kernel's output phase is one
+// linear copy (whole lines; no slot table, one store per value instead of two of which the hardware drops one), and the PCG's update
+// launch gathers every row the same way (no divergence between rows with and without slots).  Same number of rows written and read as
+// with the shared rows only; measured at the headline size: application 112.0 -> 111.0 us, solve of a batch 108.0 -> 106.5 ms, three
+// contexts 126.3 -> 128.6 points/s (profiles/r04_aa_*).  remo_debug_tune key 37 = 0 (probe builds): shared rows only.
+int g_patch_all_slab = 1;
 void set_patch_all_slab(int v) { g_patch_all_slab = v ? 1 : 0; }
 int g_patch_trim = 1;
 void set_patch_trim(int v) { g_patch_trim = v; }
@@ -1169,17 +1195,19 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     int32_t *prow = ar.lo<int32_t>(size_t(out.npatch) * rows_cap + 1);
     int32_t *pout = ar.lo<int32_t>(size_t(out.npatch) * rows_cap + 1);
     int32_t *bptr = ar.lo<int32_t>(size_t(n) + 2);
+    out.all_slab = (g_patch_all_slab && !g_patch_slab_rows) ? 1 : 0;
     out.nslot_cap = out.npatch * int64_t(rows_cap) < nt * 20 ? out.npatch * int64_t(rows_cap) : nt * 20;
     int32_t *bslot = ar.lo<int32_t>(size_t(out.nslot_cap) + 2);
     const size_t mark = ar.hi_mark();
     int32_t *bcnt = ar.hi<int32_t>(size_t(n) + 2);
-    int32_t *pbcnt = ar.hi<int32_t>(size_t(out.npatch) + 2), *pboff = ar.hi<int32_t>(size_t(out.npatch) + 2);
+    int32_t *pboff = ar.lo<int32_t>(size_t(out.npatch) + 2);
+    int32_t *pbcnt = ar.hi<int32_t>(size_t(out.npatch) + 2);
     (void)hipMemsetAsync(flag_and_max, 0, 3 * sizeof(int32_t), s);
     (void)hipMemsetAsync(prow, 0xFF, sizeof(int32_t) * (size_t(out.npatch) * rows_cap + 1), s);   // -1 behind a patch's last row
     (void)hipMemsetAsync(pbcnt + out.npatch, 0, sizeof(int32_t), s);
-    hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt, g_patch_all_slab);
+    hipLaunchKernelGGL(k_patch_row_slots, dim3(int((n + 1 + 255) / 256)), dim3(256), 0, s, n, E, sy.adjptr, sy.adj, bcnt, out.all_slab);
     hipLaunchKernelGGL(k_patch_build, dim3(int(out.npatch)), dim3(256), size_t(npad) * 8, s, nt, E, rows_cap, npad, sy.eldof, sy.adjptr, sy.adj,
-                       lidx, pcount, pbcnt, prow, pout, flag_and_max, flag_and_max + 1, g_patch_all_slab);
+                       lidx, pcount, pbcnt, prow, pout, flag_and_max, flag_and_max + 1, out.all_slab);
     size_t tb1 = 0, tb2 = 0;
     (void)rocprim::exclusive_scan(nullptr, tb1, bcnt, bptr, int32_t(0), size_t(n + 1), rocprim::plus<int32_t>(), s);
     (void)rocprim::exclusive_scan(nullptr, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
@@ -1191,7 +1219,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
                        sy.adjptr, sy.adj, (const int32_t *)bptr, bslot, g_patch_slab_rows);
     (void)hipMemcpyAsync(flag_and_max + 2, bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use
     ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
-    out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.bptr = bptr; out.bslot = bslot;
+    out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.pboff = pboff; out.bptr = bptr; out.bslot = bslot;
 }
 
 template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s, bool defer) {

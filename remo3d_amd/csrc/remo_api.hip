@@ -152,7 +152,9 @@ int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves abov
 int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
 int g_dot_bins = 1;   // key 28: 1 = the patches add their <p, A p> straight into the update launch's rows (default), 0 = a row per patch + k_patch_dot
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
+#ifdef REMO_PROBES
 int g_extra_apply = 0; // key 36 (probe builds): extra operator applications (apply + shared-row sums, results discarded) per PCG step: what a step with more applications would cost
+#endif
 int g_compact = 1;   // key 13: 1 = Chebyshev launches read a compact copy of the vertex block, 0 = the leading entries of A's rows in place
 constexpr int64_t kCompactPerRow = 48;   // capacity of the compact copy per vertex (3D P1 rows hold ~15 entries; a copy that does not fit is not used)
 
@@ -785,12 +787,13 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         b->A.pair_begin = pair_begin; b->A.pair_end = pair_end;
         b->A.vertex_block_only = lite;
         // (the patch kernel's buffer descriptors address the slab and x with 32-bit byte offsets: beyond 4 GB the CSR product stays)
-        const bool slab_fits = uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
+        // (all_slab, the product's form: every patch addresses its own block of the slab through a descriptor of its own - only x is bound by this)
+        const bool slab_fits = (ptab.all_slab || uint64_t(nt) * 20 * uint64_t(kmax) * 8 < 0xFFFFF000ull) && uint64_t(n) * uint64_t(kmax) * 8 < 0xFFFFF000ull;
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
         // (an element list without locality) sends op = 0 on to the CSR product and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
         const size_t patch_lds = ptab.block > 0 ? patch_lds_bytes(h_patch[1], kmax, ptab.block) : 0;   // what k_patch_apply asks for (kernels.hip patch_applies)
-        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && slab_fits && n < (int64_t(1) << 24) && h_patch[2] < (1 << 24) && patch_lds <= kPatchLdsLimit;
+        const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && slab_fits && n < (int64_t(1) << 24) && h_patch[2] < (ptab.all_slab ? 0x7FFFFFF0 : (1 << 24)) && patch_lds <= kPatchLdsLimit;
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && dim == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is too large)");
         const bool patch_op = patch_ok;

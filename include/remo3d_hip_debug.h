@@ -71,6 +71,7 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  *    LDS-DMA / through registers (round 4: parity-green, 138 / 111.5 us against 112 at size L: DESIGN.md section 8), 35 their number per XCD
  *    (0 = as many as stay resident); 36 extra operator applications per PCG step (results discarded: what more applications would cost);
  *    37: 0 = only the rows shared by several patches go through the slab, the others straight to y (the form before round 4's last build).
+ *    38: the workgroups of the patch kernel's first round start (slot on the CU) x this many 64-clock units apart (de-phasing probe: no gain).
  *    remo_debug_patch_phases[_p] and remo_debug_grid_barrier also need that build. */
 int remo_debug_tune(int32_t key, int32_t value);
 

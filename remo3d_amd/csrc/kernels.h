@@ -90,6 +90,7 @@ struct PatchTables {
     const int32_t *bslot = nullptr;    // slab slot of each (row, patch) pair; the slab itself is patch-major (a patch's shared rows are one block)
     const double *C = nullptr;         // [nt][6] metric terms (launch_metric_terms)
     int64_t nslot_cap = 0;             // upper bound of bptr[n]: rows of the slab
+    int stagger = 0;                   // probe builds (remo_debug_tune key 38)
 };
 template <class T> struct PatchOpT {
     PatchTables t;
@@ -148,6 +149,7 @@ template <class T> void launch_spmm(const CsrViewT<T> &A, int k, const T *x, T *
 template <class T> void launch_patch_spmm(const CsrViewT<T> &A, int k, const T *x, T *y, double *part, const double *scal, int nblocks, hipStream_t s, int step, bool defer);   // patch.hip
 template <class T> bool pcg_update_folds(const PcgBuffersT<T> &b);   // the update launch takes the first Chebyshev step along (and gathers q)
 void set_patch_mode(int mode);
+void set_patch_stagger(int units);   // key 38 (probe builds)
 void set_patch_all_slab(int on);   // remo_debug_tune key 37 (probe builds): 0 = only the shared rows go through the slab (the form of rounds 3-4)
 void set_patch_persist(int on);   // remo_debug_tune key 34 (patch.hip k_patch_apply_p)
 void set_patch_wgs_per_xcd(int n);   // key 35

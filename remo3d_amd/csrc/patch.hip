@@ -205,6 +205,12 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     if (scal && solve_done(scal, step)) return;
     // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
 #define REMO_STAMP(k) if constexpr (MODE == 4) { if (threadIdx.x == 0) stamps[(int64_t(blockIdx.x) << 3) + (k)] = __builtin_readcyclecounter(); }
+#ifdef REMO_PROBES
+    if (tb.stagger > 0 && blockIdx.x < 2048) {     // probe (key 38): the first workgroups of a CU start one after the other, not together
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < slot * tb.stagger; i += 100) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     REMO_STAMP(0)
     constexpr int NL = K;
     constexpr int U = kPatchPasses;                      // loads in flight per lane: one trip over up to U * (256 / K) rows
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
         }
         __syncthreads();    // every lane has read its x values: the staging area becomes the accumulators
         REMO_STAMP(3)
-        for (int j = tid; j < rows_p * K; j += BLK) ya[j] = 0.0;
+        for (int j = 2 * tid; j < rows_p * K; j += 2 * BLK) { ya[j] = 0.0; ya[j + 1] = 0.0; }     // (16 bytes per lane; an odd count clears one value of the next row: unused, or the zero row)
         if (tid < K) ya[rows * K + tid] = 0.0;
         __syncthreads();
         REMO_STAMP(4)
@@ -392,7 +398,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     REMO_STAMP(3)
     // the accumulators are fp64 whatever T is: ds_add_f32 runs at about a lane per clock on this chip (measured: 204 of the 304 us
     // of the fp32 kernel at 443 k tetrahedra were its 20 atomics per lane; ds_add_f64 costs 4 us there)
-    for (int j = tid; j < rows_p * K; j += BLK) ya[j] = 0.0;
+    for (int j = 2 * tid; j < rows_p * K; j += 2 * BLK) { ya[j] = 0.0; ya[j + 1] = 0.0; }     // (16 bytes per lane; an odd count clears one value of the next row: unused, or the zero row)
     if (tid < K) ya[rows * K + tid] = 0.0;
     __syncthreads();
     REMO_STAMP(4)
@@ -442,15 +448,23 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // its own buffer descriptor (64-bit base, the patch's rows as its range): small offsets, no limit on the slab's size, and the
     // hardware drops what lies behind the patch's last row
     if (MODE != 3 && lin) {
+        // 16 bytes per lane and store (two fp64 / four fp32 values; the accumulators come out of LDS 16 bytes at a time as well): half
+        // the store instructions of a value per lane.  A store that straddles the end of the block loses its dwords beyond it
+        // (buffer stores of several dwords are range-checked dword by dword).
+        constexpr int VEC = 16 / int(S);
         const rsrc_t rp = make_rsrc(Yb + slab0 * K, uint64_t(rows_own) * K * S);
         auto put = [&](auto np_c, int m0) {
             constexpr int NP = decltype(np_c)::value;
-            T v[NP][1];
+            constexpr int NQ = (NP * EK * K + VEC * BLK - 1) / (VEC * BLK);      // NP passes of EK rows = NP EK K values from value m0 K on
+            T v[NQ][VEC];
 #pragma unroll
-            for (int u = 0; u < NP; ++u) v[u][0] = T(ya[(m0 + el + EK * u) * K + c0]);    // (behind the staged rows: whatever LDS holds, never stored)
+            for (int q = 0; q < NQ; ++q) {
+                const int j = m0 * K + VEC * (tid + BLK * q);                     // (behind the patch's rows: whatever LDS holds, never stored)
 #pragma unroll
-            for (int u = 0; u < NP; ++u)
-                buf_store<T, 1>(rp, off_mask == 0 ? uint32_t((m0 + el + EK * u) * K + c0) * S : kOutOfRange, v[u]);
+                for (int i = 0; i < VEC; ++i) v[q][i] = T(ya[j + i]);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) buf_store<T, VEC>(rp, uint32_t(m0 * K + VEC * (tid + BLK * q)) * S, v[q]);
         };
         REMO_PASSES(put)
     }
@@ -1153,6 +1167,10 @@ void set_patch_wgs_per_xcd(int v) { g_patch_wgs_per_xcd = v > 0 ? v : 0; }
 // contexts 126.3 -> 128.6 points/s (profiles/r04_aa_*).  remo_debug_tune key 37 = 0 (probe builds): shared rows only.
 int g_patch_all_slab = 1;
 void set_patch_all_slab(int v) { g_patch_all_slab = v ? 1 : 0; }
+#ifdef REMO_PROBES
+int g_patch_stagger = 0;       // key 38: the workgroups of the first round wait (blockIdx / 256) x this many 64-clock units before they start (de-phasing the four workgroups of a CU)
+void set_patch_stagger(int v) { g_patch_stagger = v > 0 ? v : 0; }
+#endif
 int g_patch_trim = 1;
 void set_patch_trim(int v) { g_patch_trim = v; }
 int g_patch_spread = 4;
@@ -1224,7 +1242,12 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
 
 template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s, bool defer) {
     const PatchOpT<T> &P = *A.patch;
+#ifdef REMO_PROBES
+    PatchTables tb = P.t;
+    tb.stagger = g_patch_stagger;
+#else
     const PatchTables &tb = P.t;
+#endif
     const int64_t per = (tb.npatch + 7) / 8;
     double *pp = part ? P.ppart : nullptr;
     const dim3 grid(int(per * 8));

@@ -1516,6 +1516,7 @@ int remo_debug_tune(int32_t key, int32_t value) {
     else if (key == 35) set_patch_wgs_per_xcd(value);
     else if (key == 36) g_extra_apply = value;
     else if (key == 37) set_patch_all_slab(value);
+    else if (key == 38) set_patch_stagger(value);
     else set_spmm_tuning(key, value);
     return 0;
 #else

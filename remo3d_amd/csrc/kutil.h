@@ -28,6 +28,24 @@ template <int K> __device__ __forceinline__ void block_sum(double (&v)[K], doubl
     }
 }
 
+// The same sums (same order: bit-identical), handed out one per thread: thread c < K returns the sum of v[c] over the block, the others 0.
+// For a writer that wants "column threadIdx.x": choosing among the K registers by a run-time index (pick below) makes the compiler
+// put the array into scratch memory when K >= 3 - 48 bytes stored per lane, 74 MB per application of the patch operator at size L.
+template <int K> __device__ __forceinline__ double block_sum_column(double (&v)[K], double *smem /* [16*K] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int c = 0; c < K; ++c) v[c] = wave_sum(v[c]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < K; ++c) smem[wave * K + c] = v[c];
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x < K)
+        for (int w = 0; w < nw; ++w) s += smem[w * K + threadIdx.x];
+    return s;
+}
+
 // Sum of per-block partials part[nb][K] in a fixed order; result in every thread.
 template <int K> __device__ __forceinline__ void reduce_partials(const double *part, int nb, double (&out)[K], double *smem) {
     double v[K];

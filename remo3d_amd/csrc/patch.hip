@@ -132,7 +132,9 @@ __global__ void __launch_bounds__(256) k_patch_build(int64_t nt, int E, int rows
     if (tid == 0) {
         int t = 0;
         for (int q = 0; q < 256; ++q) t += cnts[q];
-        pbcnt[p] = t;
+        // all_rows: a patch's block of the slab begins on a 64-byte line in fp64 and fp32 storage alike (16 rows of k values): the linear
+        // output phase then stores whole lines only
+        pbcnt[p] = all_rows ? ((t + 15) & ~15) : t;
     }
 }
 
@@ -495,12 +497,12 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
         double dot[K];
 #pragma unroll
         for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
-        block_sum<K>(dot, smem);
+        const double mine = block_sum_column<K>(dot, smem);     // (not block_sum + pick: that went through scratch memory, kutil.h)
         if (tid < K) {
             // pbins: straight into the consumer's rows (kPqBins of them, patches p, p + kPqBins, ... share one; return-less atomic
             // adds performed at the memory side, complete when the launch ends) instead of a row per patch that a launch folds
-            if (pbins) (void)__hip_atomic_fetch_add(pbins + (p % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else ppart[p * K + tid] = pick<K>(dot, tid);
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (p % kPqBins) * K + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[p * K + tid] = mine;
         }
     }
     REMO_STAMP(7)
@@ -786,10 +788,10 @@ __global__ void __launch_bounds__(256, 2) k_patch_apply_p(PatchTables tb, int R,
         double dot[K];
 #pragma unroll
         for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
-        block_sum<K>(dot, smem);
+        const double mine = block_sum_column<K>(dot, smem);
         if (tid < K) {
-            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else ppart[int64_t(p0) * K + tid] = pick<K>(dot, tid);
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[int64_t(p0) * K + tid] = mine;
         }
         if (!pbins)      // one row of sums per PATCH is what the folding launches read: this workgroup's other patches contribute zero
             for (int64_t j = tid; j < int64_t(p1 - p0 - 1) * K; j += BLK) ppart[int64_t(p0 + 1) * K + j] = 0.0;
@@ -1062,10 +1064,10 @@ __global__ void __launch_bounds__(256, 3) k_patch_apply_r(PatchTables tb, int R,
         double dot[K];
 #pragma unroll
         for (int c = 0; c < K; ++c) dot[c] = (c == c0) ? d0 : 0.0;
-        block_sum<K>(dot, smem);
+        const double mine = block_sum_column<K>(dot, smem);
         if (tid < K) {
-            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, pick<K>(dot, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else ppart[int64_t(p0) * K + tid] = pick<K>(dot, tid);
+            if (pbins) (void)__hip_atomic_fetch_add(pbins + (blockIdx.x % kPqBins) * K + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ppart[int64_t(p0) * K + tid] = mine;
         }
         if (!pbins)
             for (int64_t j = tid; j < int64_t(p1 - p0 - 1) * K; j += BLK) ppart[int64_t(p0 + 1) * K + j] = 0.0;
@@ -1235,7 +1237,7 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     hipLaunchKernelGGL(k_patch_zero_rows, dim3(1024), dim3(256), 0, s, nt * 20, lidx, (const int32_t *)(flag_and_max + 1));
     hipLaunchKernelGGL(k_patch_slots, dim3(int(out.npatch)), dim3(256), 0, s, E, rows_cap, (const int32_t *)pcount, (const int32_t *)pboff, (const int32_t *)prow, pout,
                        sy.adjptr, sy.adj, (const int32_t *)bptr, bslot, g_patch_slab_rows);
-    (void)hipMemcpyAsync(flag_and_max + 2, bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use
+    (void)hipMemcpyAsync(flag_and_max + 2, out.all_slab ? pboff + out.npatch : bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use (all_slab: blocks padded to 16 rows)
     ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
     out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.pboff = pboff; out.bptr = bptr; out.bslot = bslot;
 }

@@ -567,7 +567,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         need += size_t(nt) * NT * 8 + size_t(nnz_max) * 8 + size_t(ndof_max) * 8 * (1 + 5 * size_t(kmax)) + size_t(nv + 64) * 8 * 4 * size_t(kmax);
         // the patch operator is 3D only; a 2D batch always runs on the CSR product, whatever `op` says
         const bool want_patch = dim == 3 && (o.op == 3 || o.op == 0);
-        if (want_patch) need += patch_arena_bytes(nt, ndof_max, kmax) + size_t(nt) * 20 * size_t(kmax) * 8;   // tables + boundary slab (upper bound)
+        if (want_patch) need += patch_arena_bytes(nt, ndof_max, kmax) + (size_t(nt) * 21 + 64) * size_t(kmax) * 8;   // tables + slab (upper bound: a row per element dof, and every patch's block padded to 16 rows)
         need += size_t(kMaxPartialBlocks) * 8 * 8 * 3 + size_t(npts) * (N + 8) * 8 + (1 << 20);
         need += size_t(nv + 64) * 200 * 20 + size_t(nv + 64) * 8;   // squared vertex block (paired Chebyshev steps)
         need += size_t(nv + 64) * kCompactPerRow * 16 + size_t(nv + 64) * 8;   // compact vertex block (+ its fp32 values)

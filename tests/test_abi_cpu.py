@@ -96,5 +96,25 @@ def test_probe_keys_are_not_in_the_product_library():
     L = _lib.load()
     for key, default in ((3, -1), (6, 1), (9, 1), (13, 1), (15, 1), (16, 0), (17, 1), (18, 1), (22, 1), (24, 1)):
         assert L.remo_debug_tune(key, default) == 0, key
-    for key in (0, 1, 2, 4, 5, 7, 8, 19, 20, 21, 23, 26, 27, 28, 32, 33, 34, 35, 36, 99):
+    for key in (0, 1, 2, 4, 5, 7, 8, 19, 20, 21, 23, 26, 27, 28, 32, 33, 34, 35, 36, 37, 38, 99):
         assert L.remo_debug_tune(key, 0) == -1, key
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """Every kernel of ours in the BUILT library keeps its data in registers and LDS (private segment = 0 bytes in the code objects'
+    metadata): round 4 found k_patch_apply storing 48 bytes per lane to scratch - an array of K sums chosen by a run-time index,
+    not a spill, so the compiler's summary said "vgpr-spill 0" - which cost 13 % of the operator's time.  rocPRIM's radix sort
+    (a library kernel of the numbering phase) is the one exception."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_objects
+    from remo3d_amd import _lib
+    if not os.path.exists(code_objects.READELF):
+        pytest.skip("llvm-readelf not in this image")
+    ks = code_objects.kernels(_lib.LIB_PATH)
+    names = code_objects.demangle([k["name"] for k in ks])
+    ours = [(k, d) for k, d in zip(ks, names) if d.startswith("remo::")]
+    assert len(ours) > 100, len(ours)
+    assert any("k_patch_apply<double, 5" in d for _, d in ours) and any("k_pcg_update<double, 5" in d for _, d in ours)
+    bad = ["%s: %d bytes per lane" % (d, k["scratch"]) for k, d in ours if k["scratch"] != 0]
+    assert not bad, bad

@@ -105,9 +105,11 @@ template <class T> struct PatchOpT {
 constexpr int kPatchPasses = REMO_PATCH_PASSES;   // staging passes a lane's registers hold (k_patch_apply)
 // dynamic LDS of k_patch_apply: staged k-wide rows (later the fp64 accumulators; + the zero row and one of slack) and the two
 // row tables padded to whole staging passes; a workgroup may ask for 64 KB less the kernel's static 128 k bytes
-inline size_t patch_lds_bytes(int lds_rows, int k, int block) {
+// (all_slab, the product's form: no row tables in LDS - the row numbers go straight into registers - so five workgroups of a 700-row batch
+// share a CU's 160 KB instead of four)
+inline size_t patch_lds_bytes(int lds_rows, int k, int block, bool all_slab) {
     const int pass = kPatchPasses * (block / k);
-    return size_t(lds_rows + 2) * size_t(k) * 8 + size_t((lds_rows + pass - 1) / pass) * pass * 8;
+    return size_t(lds_rows + 2) * size_t(k) * 8 + (all_slab ? size_t(0) : size_t((lds_rows + pass - 1) / pass) * pass * 8);
 }
 constexpr size_t kPatchLdsLimit = 63 * 1024;
 

@@ -599,7 +599,7 @@ template <class T, int K> static void spmm_dispatch(const CsrViewT<T> &A, const 
 }
 
 template <class T> bool patch_applies(const CsrViewT<T> &A, int k) {
-    return A.patch && k * A.patch->t.E <= A.patch->t.block && patch_lds_bytes(A.patch->lds_rows, k, A.patch->t.block) <= kPatchLdsLimit;
+    return A.patch && k * A.patch->t.E <= A.patch->t.block && patch_lds_bytes(A.patch->lds_rows, k, A.patch->t.block, A.patch->t.all_slab != 0) <= kPatchLdsLimit;
 }
 template bool patch_applies<double>(const CsrViewT<double> &, int);
 template bool patch_applies<float>(const CsrViewT<float> &, int);

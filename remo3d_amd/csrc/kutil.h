@@ -98,6 +98,16 @@ __device__ __forceinline__ bool solve_done(const double *scal, int step) {
     return d != 0 && d <= step;
 }
 
+// A load the compiler sends down the VECTOR-memory path although its address is the same for every lane (the address passes through
+// vector registers it cannot see into).  For a word that would otherwise make a wave's scalar loads (which return out of order: any use
+// waits for all of them) queue behind a slow one.
+template <class V> __device__ __forceinline__ V load_as_vector(const V *p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    uint32_t lo = uint32_t(a), hi = uint32_t(a >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return *reinterpret_cast<const V __attribute__((address_space(1))) *>((uint64_t(hi) << 32) | lo);   // (global, not flat: a flat load counts as an LDS access too)
+}
+
 // ---- buffer accesses with the hardware range check: a lane with nothing to load / store hands the instruction an offset
 // beyond the descriptor's range - the load returns 0, the store is dropped, and neither sends a request down the
 // vector-memory path.  No branch around the access, so the compiler keeps all of them in flight together.

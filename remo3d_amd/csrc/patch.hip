@@ -204,7 +204,17 @@ template <class T, int K, int BLK, int MODE = 0, bool LEAN = false>
 __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
                                                      double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps,
                                                      double *__restrict__ pbins) {
-    if (scal && solve_done(scal, step)) return;
+    // every row of the patch goes to its block of the slab (PatchTables::all_slab; the product has no other form)
+#ifdef REMO_PROBES
+    const bool lin = tb.all_slab != 0;
+#else
+    constexpr bool lin = true;
+#endif
+    // lin: the "solve is over" word is asked for HERE but looked at when the row numbers are there (it travels with them, as a vector
+    // load, so that no scalar load of the prologue queues behind a word another XCD wrote: one round trip instead of two)
+    int done_word = 0;
+    if (lin) { if (scal) done_word = load_as_vector(reinterpret_cast<const int *>(scal + kDoneSlot)); }
+    else if (scal && solve_done(scal, step)) return;
     // MODE 4: wave 0 of every workgroup leaves the clock at the phase boundaries (remo_debug_patch_phases)
 #define REMO_STAMP(k) if constexpr (MODE == 4) { if (threadIdx.x == 0) stamps[(int64_t(blockIdx.x) << 3) + (k)] = __builtin_readcyclecounter(); }
 #ifdef REMO_PROBES
@@ -235,18 +245,24 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // average patch has 0.6 of the rows of the largest, and a pass without rows still cost its instructions.  The number of passes
     // is a compile-time constant of the code that runs (a switch over 1 .. U: guards inside one unrolled loop keep the loads from
     // going out together and cost what the shorter walk saves); remo_debug_tune key 33 = 0: the largest patch's count for all
-    const int rows_own = tb.pcount[p];
-    // every row of the patch goes to its block of the slab (PatchTables::all_slab; the product has no other form): no slot table
-#ifdef REMO_PROBES
-    const bool lin = tb.all_slab != 0;
-#else
-    constexpr bool lin = true;
-#endif
-    const int64_t slab0 = lin ? int64_t(tb.pboff[p]) : 0;
-    const int rows_p = (tb.trim && rows_own < rows) ? rows_own : rows;
-    const int npass = (rows_p + EK - 1) / EK;
     const int el = tid / NL, c0 = tid - el * NL;
     const int32_t off_mask = tid < EK * K ? 0 : int32_t(0x80000000);   // or-ed into a row number: negative = no row for this lane
+    // lin: the patch's row count and the row numbers THIS lane stages (local rows el, el + EK, ...: the first U of them) are requested
+    // together, straight into registers - no table in LDS, no barrier before the x rows can be asked for.  (The row count as a vector
+    // load too: a scalar load would make every later scalar wait - kernel arguments, factor tables - wait for it.)
+    const rsrc_t rpr = make_rsrc(prow, uint64_t(tb.rows_cap) * 4);
+    int32_t r0[U];
+    int rows_own_v = 0, slab0_v = 0;     // (slab0_v: first slab slot of the patch, wanted by the output phase)
+    if (lin) {
+        rows_own_v = load_as_vector(tb.pcount + p);
+        slab0_v = load_as_vector(tb.pboff + p);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int32_t t[1];
+            buf_load<int32_t, 1>(rpr, off_mask == 0 ? uint32_t(el + EK * u) * 4u : kOutOfRange, t);
+            r0[u] = t[0];
+        }
+    }
     // the elements of a wave are taken from four runs of the patch's list instead of one (remo_debug_tune key 32: 0 = one run):
     // consecutive elements of the sorted list share their smallest vertices, i.e. they add into the same LDS rows in the same
     // instruction, which serialises - application 138.0 / 125.4 us against 141.3 / 128.2 at 443 k / 424 k tetrahedra.  Lane group el
@@ -268,19 +284,20 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
     // patch's last row, so no row count has to arrive first; the LDS copies are padded with -1 to whole passes of 1b.
     // The table loads are issued BEFORE the element's own data (local rows, metric terms), which is wanted much later: loads
     // return in order, and the wait in front of the LDS copies then covers the tables only.
+    // (buffer loads: a lane without an element hands over an offset out of range instead of branching around the loads - with a branch
+    // the compiler's count of loads in flight is the smaller one of the two paths, and every later wait for a row number would wait for
+    // these, the slowest loads of the prologue, too)
+    const rsrc_t rli = make_rsrc(tb.lidx, uint64_t(tb.nt) * 40), rcm = make_rsrc(tb.C, uint64_t(tb.nt) * 48);
     auto element_data = [&]() {
-        if (active) {
-            const uint32_t *pl = reinterpret_cast<const uint32_t *>(tb.lidx + e * 20);   // 40-byte records: 8-byte aligned
-#pragma unroll
-            for (int q = 0; q < 10; ++q) li[q] = pl[q];
-            if constexpr (!(LEAN && MODE != 2)) {
-                const double *ce = tb.C + e * 6;                           // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) cm[q] = ce[q];
-            }
-        }
+        buf_load<uint32_t, 10>(rli, active ? uint32_t(e) * 40u : kOutOfRange, li);   // 40-byte records: 8-byte aligned
+        if constexpr (!(LEAN && MODE != 2)) buf_load<double, 6>(rcm, active ? uint32_t(e) * 48u : kOutOfRange, cm);   // metric terms (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
     };
-    for (int m0 = tid; m0 < rows_pad || m0 == tid; m0 += 4 * BLK) {
+    if (lin) element_data();
+    const int rows_own = lin ? __builtin_amdgcn_readfirstlane(rows_own_v) : tb.pcount[p];
+    if (lin && __builtin_amdgcn_readfirstlane(done_word) != 0 && __builtin_amdgcn_readfirstlane(done_word) <= step) return;   // (solve_done; uniform)
+    const int rows_p = (tb.trim && rows_own < rows) ? rows_own : rows;
+    const int npass = (rows_p + EK - 1) / EK;
+    for (int m0 = tid; !lin && (m0 < rows_pad || m0 == tid); m0 += 4 * BLK) {
         int32_t r[4], o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -295,7 +312,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
             if (m < rows_pad) { trow[m] = r[u]; if (!lin) tout[m] = o[u]; }
         }
     }
-    __syncthreads();
+    if (!lin) __syncthreads();
     REMO_STAMP(1)
     // 1b. stage the patch's x rows, ONE VALUE per lane and load: in pass u lane (el, c0) takes column c0 of local row el + EK u
     // (EK = 256 / K rows per pass), i.e. value tid + EK K u of the staged image - neighbouring lanes read neighbouring addresses
@@ -330,7 +347,33 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
             for (int m0 = 0; m0 < rows_p; m0 += U * EK) fn(std::integral_constant<int, U>{}, m0);                         \
     }
     static_assert(U == 12, "REMO_PASSES lists the cases 1 .. U");
-    REMO_PASSES(stage)
+    // lin: the same walk with the row numbers from registers (a patch with more than U passes of rows - the largest few of a batch -
+    // asks for the numbers of its later chunks when it gets there)
+    auto stage_lin = [&](auto np_c, int m0) {
+        constexpr int NP = decltype(np_c)::value;
+        int32_t r[NP];
+        T v[NP][1];
+        if (m0 == 0) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) r[u] = r0[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                int32_t t[1];
+                buf_load<int32_t, 1>(rpr, off_mask == 0 ? uint32_t(m0 + el + EK * u) * 4u : kOutOfRange, t);
+                r[u] = t[0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) r[u] = (off_mask == 0 && m0 + el + EK * u < rows_own) ? r[u] : -1;
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+            buf_load<T, 1>(rx, r[u] >= 0 ? __umul24(uint32_t(r[u]), K * S) + uint32_t(c0) * S : kOutOfRange, v[u]);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) xs[r[u] >= 0 ? uint32_t((m0 + el + EK * u) * K + c0) : slack] = v[u][0];
+    };
+    if (lin) { REMO_PASSES(stage_lin) }
+    else { REMO_PASSES(stage) }
     if (tid < 2 * K) xs[rows * K + tid] = T(0);
     __syncthreads();
     REMO_STAMP(2)
@@ -454,7 +497,7 @@ __global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply
         // the store instructions of a value per lane.  A store that straddles the end of the block loses its dwords beyond it
         // (buffer stores of several dwords are range-checked dword by dword).
         constexpr int VEC = 16 / int(S);
-        const rsrc_t rp = make_rsrc(Yb + slab0 * K, uint64_t(rows_own) * K * S);
+        const rsrc_t rp = make_rsrc(Yb + int64_t(__builtin_amdgcn_readfirstlane(slab0_v)) * K, uint64_t(rows_own) * K * S);
         auto put = [&](auto np_c, int m0) {
             constexpr int NP = decltype(np_c)::value;
             constexpr int NQ = (NP * EK * K + VEC * BLK - 1) / (VEC * BLK);      // NP passes of EK rows = NP EK K values from value m0 K on
@@ -1256,7 +1299,7 @@ template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const
     double *pp2 = pp;
     double *bins = (part && defer && P.dot_bins) ? part + (step & 1) * (kPqBins * 8) : nullptr;
     auto launch = [&](auto kernel, int blk) {
-        const size_t bytes = patch_lds_bytes(P.lds_rows, K, blk);   // staged rows, later fp64 accumulators + the two (padded) row tables
+        const size_t bytes = patch_lds_bytes(P.lds_rows, K, blk, tb.all_slab != 0);   // staged rows, later fp64 accumulators (+ the two padded row tables of the probe form)
         hipLaunchKernelGGL(kernel, grid, dim3(blk), bytes, s, tb, P.lds_rows, x, y, P.Yb, pp2, scal, step, g_patch_stamps, bins);
     };
     bool launched = false;

@@ -792,7 +792,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         // patch operator: asked for, or (op = 0) whenever its tables fit; a patch with more distinct rows than the tables hold
         // (an element list without locality) sends op = 0 on to the CSR product and fails op = 3
         // (the kernel forms byte offsets of rows and slab slots with 24-bit multiplies and 32-bit buffer offsets)
-        const size_t patch_lds = ptab.block > 0 ? patch_lds_bytes(h_patch[1], kmax, ptab.block) : 0;   // what k_patch_apply asks for (kernels.hip patch_applies)
+        const size_t patch_lds = ptab.block > 0 ? patch_lds_bytes(h_patch[1], kmax, ptab.block, ptab.all_slab != 0) : 0;   // what k_patch_apply asks for (kernels.hip patch_applies)
         const bool patch_ok = want_patch && h_patch[0] == 0 && h_patch[1] > 0 && slab_fits && n < (int64_t(1) << 24) && h_patch[2] < (ptab.all_slab ? 0x7FFFFFF0 : (1 << 24)) && patch_lds <= kPatchLdsLimit;
         if (lite && !patch_ok) return fail(ctx, REMO_ERR_ARG, "only the P1 block was assembled but the patch operator cannot run on this batch: rerun with remo_opts_t.assemble = 1");
         if (o.op == 3 && dim == 3 && !patch_ok) return fail(ctx, REMO_ERR_ARG, "patch operator: a patch of the element list touches more distinct rows than its tables hold (or the mesh is too large)");

@@ -58,6 +58,9 @@ template <class T> struct PcgBuffersT {
     // q once anyway, forms them from the boundary slab itself (one launch and one pass over the slab less per step).  Set by the
     // host when the operator is the patch operator and the update launch does not gather q (no folded Chebyshev step).
     bool defer_q = false;
+    // x += alpha p is formed by the DIRECTION launch of the step (it reads the old p anyway; alpha recomputed there from the same operands:
+    // bit-identical x) instead of the update launch, which then reads neither p nor x: one pass over p less per step
+    bool x_in_direction = false;
     // patch operator, with defer_q: the patches add their <p, A p> into kPqBins rows of part_pq themselves (atomic adds; two sets of
     // rows taken in turn by step parity, the update launch of a step clears the set of the next) - no launch that folds them
     bool pq_bins = false;
@@ -166,7 +169,7 @@ int patch_elements_per_group(int kmax);
 
 template <class T> void launch_pcg_init(const CsrViewT<T> &A, int k, const T *f, const PcgBuffersT<T> &b, hipStream_t s);       // + C r0, p0
 template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);  // + C r (Chebyshev steps)
-template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s);
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s, bool add_x = true);
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s);
 void launch_vblock_bound(int64_t nv, const CsrView &A, const double *dinv, unsigned long long *out_bits, hipStream_t s);
 // B = A_vv D^-1 A_vv (and A_vv itself) on the pattern of B, rows sorted; cnt / rowptr [nv + 1], col / a / b [capacity];

@@ -656,6 +656,7 @@ template <class T> struct QViewT {
     const int32_t *bptr = nullptr, *bslot = nullptr;
     const T *Yb = nullptr;
     int ahead = 1;      // 0: the slots of a shared row one by one (remo_debug_tune key 27)
+    int skip_x = 0;     // 1: x += alpha p is left to the direction launch of the step (PcgBuffersT::x_in_direction)
 };
 template <class T> struct FoldArgsT {
     int nb_flat = 0;             // workgroups [0, nb_flat) do the flat update of the rows >= nv, the rest the vertex rows
@@ -774,7 +775,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             T di = T(0), rn = T(0);
             if (mine) {
                 di = dinv[row];
-                x[at] += a_mine * p[at];
+                if (!qv.skip_x) x[at] += a_mine * p[at];
                 rn = r[at] - a_mine * q[at];
             }
             T t[K];
@@ -811,8 +812,13 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         // x, p and r of the row are requested HERE, with the row's slab pointers, not behind the branch that gathers q: three more
         // vectors in flight while the slab slots make their two round trips
         T xv[K], pv[K], rv[K];
+        if (qv.skip_x) {      // x += alpha p rides on the direction launch, which reads p anyway: neither x nor p is touched here
 #pragma unroll
-        for (int c = 0; c < K; ++c) { xv[c] = x[i * K + c]; pv[c] = p[i * K + c]; rv[c] = r[i * K + c]; }
+            for (int c = 0; c < K; ++c) { xv[c] = T(0); pv[c] = T(0); rv[c] = r[i * K + c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < K; ++c) { xv[c] = x[i * K + c]; pv[c] = p[i * K + c]; rv[c] = r[i * K + c]; }
+        }
         if (b1 > b0) {      // a row shared by several patches: its q is still spread over the slab, one slot per patch, ascending
             // the first kSlabAhead slots without a branch and with all their loads in flight together (slot numbers, then slab
             // rows: two round trips; the plain loop made two per slot, and a wave waits for its row with the most slots) - a
@@ -853,7 +859,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
             const T a = T(alpha[c]);
             const T xi = xv[c] + a * pv[c];
             const T ri = rv[c] - a * qi[c];
-            x[i * K + c] = xi;
+            if (!qv.skip_x) x[i * K + c] = xi;
             r[i * K + c] = ri;
             acc[c] += coarse ? 0.0 : double(ri) * double(ri) * double(d);   // the vertex block's share comes from the Chebyshev kernels
         }
@@ -986,10 +992,12 @@ template <class T, int K>
 __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgsT<T> ch,
                                                        const double *__restrict__ part_rz_new, double *__restrict__ scal,
                                                        const T *__restrict__ r, T *__restrict__ p,
-                                                       const T *__restrict__ dinv) {
+                                                       const T *__restrict__ dinv, T *__restrict__ x = nullptr) {
     __shared__ double smem[16 * K];
     if (solve_done(scal, step)) return;
-    double beta[K];
+    double beta[K], alpha[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) alpha[c] = 0.0;
     if (first) {  // p0 = C r0
 #pragma unroll
         for (int c = 0; c < K; ++c) beta[c] = 0.0;
@@ -1001,6 +1009,7 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
             const double pq = scal[8 + c], rzo = scal[16 + 8 * (step & 1) + c];   // forwarded by the update launch
             const bool live = (rzo > tol2 * scal[c]) && (rzo > scal[kFloorSlot + c]) && (pq > 0.0);
             beta[c] = live ? rzn[c] / rzo : 0.0;
+            alpha[c] = live ? rzo / pq : 0.0;      // the step's alpha, from the same operands as in its update launch: the same bits
         }
         if (blockIdx.x == 0 && threadIdx.x == 0)
 #pragma unroll
@@ -1011,13 +1020,13 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
     constexpr int U = 4;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
-        T d[U], zv[U][K], pv[U][K];
+        T d[U], zv[U][K], pv[U][K], xv[U][K];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             d[u] = T(0);
 #pragma unroll
-            for (int c = 0; c < K; ++c) { zv[u][c] = T(0); pv[u][c] = T(0); }
+            for (int c = 0; c < K; ++c) { zv[u][c] = T(0); pv[u][c] = T(0); xv[u][c] = T(0); }
             if (i < n) {
                 d[u] = dinv[i];
                 const T *src = (i < ch.nv) ? ch.z : r;   // C r: Chebyshev result on the vertex block (stored as z / dinv), Jacobi elsewhere
@@ -1026,6 +1035,9 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
                 if (!first)
 #pragma unroll
                     for (int c = 0; c < K; ++c) pv[u][c] = p[i * K + c];
+                if (x && !first)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) xv[u][c] = x[i * K + c];
             }
         }
 #pragma unroll
@@ -1036,6 +1048,9 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
                 for (int c = 0; c < K; ++c) {
                     const T zi = d[u] * zv[u][c];
                     p[i * K + c] = first ? zi : zi + T(beta[c]) * pv[u][c];
+                    // x += alpha p of THIS step, with the old direction that is in registers anyway (PcgBuffersT::x_in_direction):
+                    // the update launch then neither reads p nor touches x - one pass over p less per step
+                    if (x && !first) x[i * K + c] = xv[u][c] + T(alpha[c]) * pv[u][c];
                 }
         }
     }
@@ -1572,6 +1587,7 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     }
     QViewT<T> qv;
     if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; qv.ahead = g_slab_ahead; }
+    qv.skip_x = b.x_in_direction ? 1 : 0;
     const bool bins = b.pq_bins && b.defer_q && A.patch && !folded;
     const double *pq_rows = bins ? b.part_pq + (step & 1) * (kPqBins * 8) : b.part_pq;
     double *pq_clear = bins ? b.part_pq + ((step + 1) & 1) * (kPqBins * 8) : nullptr;
@@ -1625,12 +1641,15 @@ void launch_pcg_replace(const CsrViewT<float> &A, const CsrViewT<double> &A64, i
     launch_cheb(A, k, step, b, nxt, s);
 }
 
-template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s) {
+// add_x: this launch also forms x += alpha p of the step (b.x_in_direction and the step's update launch left x alone; a residual
+// replacement of the mixed mode updates x itself)
+template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int step, double tol2, const PcgBuffersT<T> &b, hipStream_t s, bool add_x) {
     const int64_t n = A.n;
     const int g = b.nb_vec;
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<T> ch = cheb_args(b);
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv));
+    T *xp = (add_x && b.x_in_direction) ? b.x : nullptr;
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv, xp));
 }
 
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s) {
@@ -1641,7 +1660,7 @@ template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &
 #define REMO_INSTANTIATE_PCG(T)                                                                                          \
     template void launch_pcg_init<T>(const CsrViewT<T> &, int, const T *, const PcgBuffersT<T> &, hipStream_t);          \
     template void launch_pcg_update<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);      \
-    template void launch_pcg_direction<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t);   \
+    template void launch_pcg_direction<T>(const CsrViewT<T> &, int, int, double, const PcgBuffersT<T> &, hipStream_t, bool);   \
     template void launch_pcg_final<T>(int, int, const PcgBuffersT<T> &, hipStream_t);
 REMO_INSTANTIATE_PCG(double)
 REMO_INSTANTIATE_PCG(float)

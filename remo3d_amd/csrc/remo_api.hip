@@ -151,6 +151,7 @@ int g_amg = 0;       // key 16: 0 = remo_opts_t.coarse decides, 1 = never the mu
 int g_chain32 = 1;   // key 15: 1 = fp32 Chebyshev chain inside fp64 solves above 32 k vertex rows (default), 0 = chain in fp64
 int g_ell = 1;        // key 24: 1 = the Chebyshev launches of 3D read the fixed-width image of the vertex block (default), 0 = its CSR form
 int g_dot_bins = 1;   // key 28: 1 = the patches add their <p, A p> straight into the update launch's rows (default), 0 = a row per patch + k_patch_dot
+int g_x_in_direction = 1;   // key 25: 1 = x += alpha p formed by the direction launch of the step (default), 0 = by the update launch
 int g_defer_q = 1;    // key 22: 1 = the PCG's update launch sums the patch operator's shared rows itself (default), 0 = k_patch_reduce does
 #ifdef REMO_PROBES
 int g_extra_apply = 0; // key 36 (probe builds): extra operator applications (apply + shared-row sums, results discarded) per PCG step: what a step with more applications would cost
@@ -212,7 +213,7 @@ ChunkResult run_pcg_t(remo_ctx *ctx, const CsrViewT<T> &A, int k, const T *d_f, 
             }
         }
         if (!replaced) launch_pcg_update(A, k, step, tol2, buf, s);
-        launch_pcg_direction(A, k, step, tol2, buf, s);
+        launch_pcg_direction(A, k, step, tol2, buf, s, !replaced);
         ++step;
         if (*done_step >= 0) { done = true; break; }   // the device froze every column: the queued launches are no-ops
         if (step % check == 0) {
@@ -820,6 +821,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
         buf.nb_spmv = spmv_grid(n, lpr);
         buf.nb_vec = vec_grid(n);
         buf.defer_q = patch_op && g_defer_q && !pcg_update_folds(buf);     // the update launch sums the shared rows of q = A p itself
+        buf.x_in_direction = g_x_in_direction != 0;
         buf.pq_bins = buf.defer_q && g_dot_bins != 0;
         if (patch_op) b->patch64.dot_bins = buf.pq_bins;
         const bool mixed = (o.precision == 1);
@@ -861,6 +863,7 @@ int remo_batch_run(remo_ctx_t *ctx, remo_batch_t *b, const remo_opts_t *opts_in,
             }
         }
         if (mixed) mx.b32.defer_q = patch_op && g_defer_q && !pcg_update_folds(mx.b32);
+        if (mixed) mx.b32.x_in_direction = g_x_in_direction != 0;
         if (mixed) { mx.b32.pq_bins = mx.b32.defer_q && g_dot_bins; if (patch_op) b->patch32.dot_bins = mx.b32.pq_bins; }
         std::vector<double> h_out(npts, std::nan(""));
         int ret = REMO_OK;
@@ -1496,6 +1499,7 @@ int remo_debug_tune(int32_t key, int32_t value) {
         case 16: g_amg = value; return 0;               // multigrid cycle on the vertex block
         case 17: g_amg32 = value; return 0;             // ... in fp32 storage
         case 18: set_element_order(value); return 0;    // elements in the caller's order
+        case 25: g_x_in_direction = value; return 0;    // x += alpha p in the direction / in the update launch
         case 22: g_defer_q = value; return 0;           // shared rows summed by k_patch_reduce / by the update launch
         case 24: g_ell = value; return 0;               // fixed-width image of the vertex block
         default: break;

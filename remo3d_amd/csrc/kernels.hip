@@ -802,7 +802,10 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         return;
     }
     const int64_t i0 = fold.nb_flat > 0 ? ch.nv : 0;
-#pragma unroll 2
+#ifndef REMO_UPD_UNROLL
+#define REMO_UPD_UNROLL 2
+#endif
+#pragma unroll REMO_UPD_UNROLL
     for (int64_t i = i0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(nb_flat) * blockDim.x) {
         const T d = dinv[i];
         const bool coarse = i < ch.nv;
@@ -1017,7 +1020,10 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
     }
     // U rows per thread are loaded before any of them is stored: p is read and written through the same pointer, and a store
     // of one row otherwise holds back the loads of the next (one row in flight per thread: 2.7 TB/s at 5.4 M rows in fp32)
-    constexpr int U = 4;
+#ifndef REMO_DIR_U
+#define REMO_DIR_U 4
+#endif
+    constexpr int U = REMO_DIR_U;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
         T d[U], zv[U][K], pv[U][K], xv[U][K];

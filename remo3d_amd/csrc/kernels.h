@@ -159,6 +159,7 @@ void set_patch_all_slab(int on);   // remo_debug_tune key 37 (probe builds): 0 =
 void set_patch_persist(int on);   // remo_debug_tune key 34 (patch.hip k_patch_apply_p)
 void set_patch_wgs_per_xcd(int n);   // key 35
 void set_patch_block(int threads);   // 256 (default) or 512
+void set_slab_masked(int v);         // key 29
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
 void set_patch_trim(int v);
 void set_patch_spread(int v);

@@ -657,6 +657,7 @@ template <class T> struct QViewT {
     const T *Yb = nullptr;
     int ahead = 1;      // 0: the slots of a shared row one by one (remo_debug_tune key 27)
     int skip_x = 0;     // 1: x += alpha p is left to the direction launch of the step (PcgBuffersT::x_in_direction)
+    uint64_t slab_bytes = 0;   // != 0 (slab below 4 GB): the slots a row does not have are not fetched at all (buffer loads, offset out of range)
 };
 template <class T> struct FoldArgsT {
     int nb_flat = 0;             // workgroups [0, nb_flat) do the flat update of the rows >= nv, the rest the vertex rows
@@ -832,6 +833,20 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
 #pragma unroll
             for (int j = 0; j < kSlabAhead; ++j) at[j] = qv.bslot[b0 + j < b1 ? b0 + j : b0];
             T part[kSlabAhead][K];
+            if (qv.slab_bytes) {
+                // a row has 1.84 slots on average (44 % of the rows exactly one, now that every row goes through the slab): a lane asks
+                // only for the slots its row has - the others get an offset beyond the buffer, which sends no request and returns 0
+                const rsrc_t rs = make_rsrc(qv.Yb, qv.slab_bytes);
+#pragma unroll
+                for (int j = 0; j < kSlabAhead; ++j)
+                    buf_load<T, K>(rs, b0 + j < b1 ? uint32_t(at[j]) * uint32_t(K * sizeof(T)) : kOutOfRange, part[j]);
+#pragma unroll
+                for (int c = 0; c < K; ++c) qi[c] = part[0][c];
+#pragma unroll
+                for (int j = 1; j < kSlabAhead; ++j)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) qi[c] += part[j][c];
+            } else {
 #pragma unroll
             for (int j = 0; j < kSlabAhead; ++j)
 #pragma unroll
@@ -843,6 +858,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                 const T w = b0 + j < b1 ? T(1) : T(0);
 #pragma unroll
                 for (int c = 0; c < K; ++c) qi[c] += w * part[j][c];
+            }
             }
             } else {
 #pragma unroll
@@ -1422,6 +1438,8 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
 }
 
 int g_slab_ahead = 1;      // remo_debug_tune key 27: 0 = the update launch walks the slab slots of a shared row one by one
+int g_slab_masked = 1;   // remo_debug_tune key 29: 0 = every row fetches four slab slots and weights the ones it does not have by zero (the form before)
+void set_slab_masked(int v) { g_slab_masked = v ? 1 : 0; }
 void set_slab_ahead(int v) { g_slab_ahead = v ? 1 : 0; }
 int vec_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
@@ -1594,6 +1612,10 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     QViewT<T> qv;
     if (b.defer_q && A.patch && !folded) { qv.bptr = A.patch->t.bptr; qv.bslot = A.patch->t.bslot; qv.Yb = A.patch->Yb; qv.ahead = g_slab_ahead; }
     qv.skip_x = b.x_in_direction ? 1 : 0;
+    if (qv.bptr && g_slab_masked) {
+        const uint64_t bytes = uint64_t(A.patch->t.nslot_cap) * uint64_t(k) * sizeof(T);
+        qv.slab_bytes = bytes < 0xFFFFF000ull ? bytes : 0;
+    }
     const bool bins = b.pq_bins && b.defer_q && A.patch && !folded;
     const double *pq_rows = bins ? b.part_pq + (step & 1) * (kPqBins * 8) : b.part_pq;
     double *pq_clear = bins ? b.part_pq + ((step + 1) & 1) * (kPqBins * 8) : nullptr;

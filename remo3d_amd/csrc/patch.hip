@@ -200,8 +200,11 @@ template <class T> __device__ __forceinline__ void lds_add(T *p, T v) {
 // LEAN: the register-lean order of phase 2 (five waves per SIMD instead of four in fp64): the gradient chain runs input by input
 // straight from the staged rows in LDS (no x[20] in registers), BEFORE the staging area is recycled; the metric terms are asked for
 // after it; the divergence chain hands every group of outputs to the LDS accumulators as soon as it is complete (no y[20]).
+#ifndef REMO_LEAN_WAVES
+#define REMO_LEAN_WAVES 5
+#endif
 template <class T, int K, int BLK, int MODE = 0, bool LEAN = false>
-__global__ void __launch_bounds__(BLK, (LEAN ? 5 * 256 / BLK : 1)) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
+__global__ void __launch_bounds__(BLK, (LEAN ? REMO_LEAN_WAVES * 256 / BLK : 1)) k_patch_apply(PatchTables tb, int rows, const T *__restrict__ x, T *__restrict__ y, T *__restrict__ Yb,
                                                      double *__restrict__ ppart, const double *__restrict__ scal, int step, long long *__restrict__ stamps,
                                                      double *__restrict__ pbins) {
     // every row of the patch goes to its block of the slab (PatchTables::all_slab; the product has no other form)

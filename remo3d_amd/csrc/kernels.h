@@ -160,6 +160,7 @@ void set_patch_persist(int on);   // remo_debug_tune key 34 (patch.hip k_patch_a
 void set_patch_wgs_per_xcd(int n);   // key 35
 void set_patch_block(int threads);   // 256 (default) or 512
 void set_slab_masked(int v);         // key 29
+void set_flat_direction(int v);      // key 30
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
 void set_patch_trim(int v);
 void set_patch_spread(int v);

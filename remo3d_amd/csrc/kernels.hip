@@ -1011,7 +1011,7 @@ template <class T, int K>
 __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int step, double tol2, int nb_rz, ChebArgsT<T> ch,
                                                        const double *__restrict__ part_rz_new, double *__restrict__ scal,
                                                        const T *__restrict__ r, T *__restrict__ p,
-                                                       const T *__restrict__ dinv, T *__restrict__ x = nullptr) {
+                                                       const T *__restrict__ dinv, T *__restrict__ x = nullptr, int flat = 0) {
     __shared__ double smem[16 * K];
     if (solve_done(scal, step)) return;
     double beta[K], alpha[K];
@@ -1033,6 +1033,74 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, int first, int
         if (blockIdx.x == 0 && threadIdx.x == 0)
 #pragma unroll
             for (int c = 0; c < K; ++c) scal[16 + 8 * ((step + 1) & 1) + c] = rzn[c];   // read by the next update launch
+    }
+    if (flat) {
+        // FLAT form (launcher: n K sizeof(T) below 4 GB): the vectors as arrays of n K values, 16 bytes per lane and access, consecutive
+        // lanes on consecutive bytes - every load and store instruction of a wave covers 1 KB of whole lines (the row form's cover 1 KB
+        // out of a 2.5 KB span, three instructions per line).  The column of a value is its index mod K: beta and alpha come from LDS
+        // (an index into registers would put them into scratch memory); the Jacobi factor of its row is an 8-byte load (an L1 hit for
+        // four of five).  Buffer accesses: the range check drops what lies behind the last value, dword by dword.
+        constexpr int VEC = 16 / int(sizeof(T));
+        constexpr uint32_t S = sizeof(T);
+        constexpr int UF = 4;
+        __syncthreads();          // (block_sum's last reads of smem)
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) { smem[c] = beta[c]; smem[K + c] = alpha[c]; }
+        }
+        __syncthreads();
+        const uint32_t N = uint32_t(n) * K, NV = uint32_t(ch.nv) * K;
+        const rsrc_t rr = make_rsrc(r, uint64_t(N) * S), rz = make_rsrc(ch.z, uint64_t(NV) * S), rp = make_rsrc(p, uint64_t(N) * S),
+                     rd = make_rsrc(dinv, uint64_t(n) * S), rx = make_rsrc(x ? x : p, uint64_t(N) * S);
+        const bool with_x = x != nullptr && !first;
+        const uint32_t span = uint32_t(gridDim.x) * blockDim.x * VEC;
+        for (uint32_t g0 = (uint32_t(blockIdx.x) * blockDim.x + threadIdx.x) * VEC; g0 < N; g0 += UF * span) {
+            T zv[UF][VEC], pv[UF][VEC], xv[UF][VEC], dv[UF][VEC];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const uint32_t e0 = g0 + u * span;
+                const uint32_t off = e0 < N ? e0 * S : kOutOfRange;
+                buf_load<T, VEC>(rr, off, zv[u]);
+                {                   // vertex rows: the vertex-block solver's result (stored pre-divided by the Jacobi factor) instead of r
+                    T zz[VEC];      // (no branch: the other lanes hand over an offset out of range and send no request)
+                    buf_load<T, VEC>(rz, e0 < NV ? e0 * S : kOutOfRange, zz);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) zv[u][v] = (e0 + v < NV) ? zz[v] : zv[u][v];
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    T one[1];
+                    buf_load<T, 1>(rd, e0 < N ? ((e0 + v) / uint32_t(K)) * S : kOutOfRange, one);
+                    dv[u][v] = one[0];
+                }
+                if (!first) buf_load<T, VEC>(rp, off, pv[u]);
+                else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) pv[u][v] = T(0);
+                }
+                if (with_x) buf_load<T, VEC>(rx, off, xv[u]);
+                else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) xv[u][v] = T(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const uint32_t e0 = g0 + u * span;
+                const uint32_t off = e0 < N ? e0 * S : kOutOfRange;
+                T pn[VEC], xn[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const uint32_t c = (e0 + v) % uint32_t(K);
+                    const T zi = dv[u][v] * zv[u][v];
+                    pn[v] = first ? zi : zi + T(smem[c]) * pv[u][v];
+                    xn[v] = xv[u][v] + T(smem[K + c]) * pv[u][v];
+                }
+                buf_store<T, VEC>(rp, off, pn);
+                if (with_x) buf_store<T, VEC>(rx, off, xn);
+            }
+        }
+        return;
     }
     // U rows per thread are loaded before any of them is stored: p is read and written through the same pointer, and a store
     // of one row otherwise holds back the loads of the next (one row in flight per thread: 2.7 TB/s at 5.4 M rows in fp32)
@@ -1439,6 +1507,8 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
 
 int g_slab_ahead = 1;      // remo_debug_tune key 27: 0 = the update launch walks the slab slots of a shared row one by one
 int g_slab_masked = 1;   // remo_debug_tune key 29: 0 = every row fetches four slab slots and weights the ones it does not have by zero (the form before)
+int g_flat_direction = 0;   // remo_debug_tune key 30: 1 = the direction launch walks its vectors as flat arrays, 16 bytes per lane
+void set_flat_direction(int v) { g_flat_direction = v ? 1 : 0; }
 void set_slab_masked(int v) { g_slab_masked = v ? 1 : 0; }
 void set_slab_ahead(int v) { g_slab_ahead = v ? 1 : 0; }
 int vec_grid(int64_t n) {
@@ -1677,7 +1747,8 @@ template <class T> void launch_pcg_direction(const CsrViewT<T> &A, int k, int st
     const double *nw = b.part_rz + ((step + 1) & 1) * (kMaxPartialBlocks * 8);
     const ChebArgsT<T> ch = cheb_args(b);
     T *xp = (add_x && b.x_in_direction) ? b.x : nullptr;
-    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv, xp));
+    const int flat = (g_flat_direction && uint64_t(n) * uint64_t(k) * sizeof(T) < 0xFFFFF000ull) ? 1 : 0;
+    REMO_K_SWITCH(k, hipLaunchKernelGGL((k_pcg_direction<T, KK>), dim3(g), dim3(256), 0, s, n, 0, step, tol2, nb_rz(b), ch, nw, b.rz0, b.r, b.p, b.dinv, xp, flat));
 }
 
 template <class T> void launch_pcg_final(int k, int step, const PcgBuffersT<T> &b, hipStream_t s) {

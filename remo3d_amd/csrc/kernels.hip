@@ -1507,7 +1507,7 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
 
 int g_slab_ahead = 1;      // remo_debug_tune key 27: 0 = the update launch walks the slab slots of a shared row one by one
 int g_slab_masked = 1;   // remo_debug_tune key 29: 0 = every row fetches four slab slots and weights the ones it does not have by zero (the form before)
-int g_flat_direction = 0;   // remo_debug_tune key 30: 1 = the direction launch walks its vectors as flat arrays, 16 bytes per lane
+int g_flat_direction = 1;   // remo_debug_tune key 30: 1 (default) = the direction launch walks its vectors as flat arrays, 16 bytes per lane; 0 = a k-wide row per lane
 void set_flat_direction(int v) { g_flat_direction = v ? 1 : 0; }
 void set_slab_masked(int v) { g_slab_masked = v ? 1 : 0; }
 void set_slab_ahead(int v) { g_slab_ahead = v ? 1 : 0; }

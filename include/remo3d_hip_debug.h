@@ -61,7 +61,8 @@ int remo_debug_grid_barrier(remo_ctx_t *ctx, int32_t nblocks, int32_t nbar, doub
  *   24  0 = Chebyshev launches walk the vertex block as CSR instead of its fixed-width image;
  *   25  0 = x += alpha p formed by the update launch instead of the direction launch of the step (bit-identical x);
  *   29  0 = the update launch fetches four slab slots for every row and weights the ones the row does not have by zero;
- *   30  0 = the direction launch takes a k-wide row per lane instead of walking its vectors as flat arrays, 16 bytes per lane.
+ *   30  0 = the direction launch takes a k-wide row per lane instead of walking its vectors as flat arrays, 16 bytes per lane;
+ *   31  0 = the update launch takes a k-wide row per lane instead of 64 rows per wave with a value per lane and pass (fp64 storage).
  *
  * (b) ONLY IN A LIBRARY BUILT WITH -DREMO_PROBES (`make -C remo3d_amd/csrc probes` -> libremo3d_hip_probes.so, loaded by the tools
  * through REMO_LIB=...): rejected experiments and ablations, some of which give WRONG RESULTS ON PURPOSE.  The product ignores them:

@@ -89,6 +89,7 @@ struct PatchTables {
     int all_slab = 1;                  // 1 (default): EVERY row of a patch goes to the patch's block of the slab, also the rows no other patch touches
                                        //   (pout[p][m] = pboff[p] + m: the kernel stores one contiguous block and y is written by whoever sums the slab);
                                        //   0 (remo_debug_tune key 37, probe builds): only the rows shared by several patches
+    const int32_t *row4 = nullptr;     // [n][4] all_slab: the first four slab slots of every row (-1 none, [3] = -2: five or more, the rest in bslot)
     const int32_t *bptr = nullptr;     // [n + 1] entries [bptr[r], bptr[r + 1]) of bslot belong to row r, one per patch that touches it (none: not shared)
     const int32_t *bslot = nullptr;    // slab slot of each (row, patch) pair; the slab itself is patch-major (a patch's shared rows are one block)
     const double *C = nullptr;         // [nt][6] metric terms (launch_metric_terms)
@@ -161,6 +162,7 @@ void set_patch_wgs_per_xcd(int n);   // key 35
 void set_patch_block(int threads);   // 256 (default) or 512
 void set_slab_masked(int v);         // key 29
 void set_flat_direction(int v);      // key 30
+void set_tile_update(int v);         // key 31
 void set_slab_ahead(int v);          // 0: slab slots of a shared row one by one in the update launch (default 1: four in flight)
 void set_patch_trim(int v);
 void set_patch_spread(int v);

@@ -657,6 +657,8 @@ template <class T> struct QViewT {
     const T *Yb = nullptr;
     int ahead = 1;      // 0: the slots of a shared row one by one (remo_debug_tune key 27)
     int skip_x = 0;     // 1: x += alpha p is left to the direction launch of the step (PcgBuffersT::x_in_direction)
+    int tile = 0;              // 1: the tile form of the update launch (k_pcg_update; remo_debug_tune key 31)
+    const int32_t *row4 = nullptr;   // PatchTables::row4 (tile form)
     uint64_t slab_bytes = 0;   // != 0 (slab below 4 GB): the slots a row does not have are not fetched at all (buffer loads, offset out of range)
 };
 template <class T> struct FoldArgsT {
@@ -800,6 +802,100 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
                 fold.stage[at] = rn;
             }
         }
+        return;
+    }
+    if (qv.tile) {
+        // TILE form (launcher: patch operator with every row in the slab and its row4 table, x left to the direction launch, no folded
+        // Chebyshev step, n K sizeof(T) and the slab below 4 GB).  A wave takes 64 rows = 64 K values at a time.  Lane l fetches the
+        // four slots of row l of the tile (ONE 16-byte load per lane: 1 KB per wave); then, pass by pass, lane l handles value
+        // 64 t + l of the tile: r as 512 consecutive bytes per wave and instruction, the slots of the value's row from the lane that
+        // holds them (ds_bpermute), and ITS column of each slab slot - the K lanes of a row read a slot's 40 bytes side by side.
+        // All 6 K loads of a lane are in flight together.  Same sums, same order as the row form (rows of five or more patches, the
+        // first vertex rows: their further slots are summed by the row's lane and handed over through LDS - another association).
+        constexpr uint32_t S = sizeof(T);
+        __shared__ double ex_lds[4 * 64 * K];
+        __syncthreads();          // (the reductions' last reads of smem)
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) smem[c] = alpha[c];
+        }
+        __syncthreads();
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t N = uint32_t(n) * K, NV = uint32_t(ch.nv) * K;
+        const rsrc_t rr = make_rsrc(r, uint64_t(N) * S), rd = make_rsrc(dinv, uint64_t(n) * S), rs = make_rsrc(qv.Yb, qv.slab_bytes),
+                     r4 = make_rsrc(qv.row4, uint64_t(n) * 16);
+        uint32_t rowof[K], colof[K];      // pass t: this lane's value is (row rowof[t] of the tile, column colof[t]) - the same for every tile
+        T al[K];
+        double accv[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const uint32_t v = 64u * t + lane;
+            rowof[t] = v / uint32_t(K); colof[t] = v - rowof[t] * uint32_t(K);
+            al[t] = T(smem[colof[t]]); accv[t] = 0.0;
+        }
+        double *exw = ex_lds + wave * (64 * K);
+        const uint32_t nwaves = uint32_t(gridDim.x) * 4u;
+        for (uint32_t R0 = (uint32_t(blockIdx.x) * 4u + wave) * 64u; R0 < uint32_t(n); R0 += nwaves * 64u) {
+            const uint32_t myrow = R0 + lane;
+            int32_t w4[4];
+            buf_load<int32_t, 4>(r4, myrow < uint32_t(n) ? myrow * 16u : kOutOfRange, w4);
+            if (myrow >= uint32_t(n)) { w4[0] = w4[1] = w4[2] = w4[3] = -1; }
+            const uint32_t e0 = R0 * uint32_t(K);
+            T rv[K], dv[K], part[K][4];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const uint32_t e = e0 + 64u * t + lane;
+                T one[1];
+                buf_load<T, 1>(rr, e < N ? e * S : kOutOfRange, one);
+                rv[t] = one[0];
+                buf_load<T, 1>(rd, e < N ? (R0 + rowof[t]) * S : kOutOfRange, one);
+                dv[t] = one[0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int32_t sj = __builtin_amdgcn_ds_bpermute(int(rowof[t] << 2), w4[j]);
+                    buf_load<T, 1>(rs, sj >= 0 ? (uint32_t(sj) * uint32_t(K) + colof[t]) * S : kOutOfRange, one);
+                    part[t][j] = one[0];
+                }
+            }
+            const bool more = w4[3] == -2;
+            const bool any_more = __builtin_amdgcn_ballot_w64(more) != 0;
+            if (any_more) {       // (wave-uniform) rows of five or more patches in this tile: their lanes sum the slots from the fourth on
+#pragma unroll
+                for (int c = 0; c < K; ++c) exw[lane * K + c] = 0.0;
+                if (more) {
+                    const int32_t c0 = qv.bptr[myrow], c1 = qv.bptr[myrow + 1];
+                    for (int32_t sl = c0 + 3; sl < c1; ++sl) {
+                        const int64_t a2 = qv.bslot[sl];
+#pragma unroll
+                        for (int c = 0; c < K; ++c) exw[lane * K + c] += double(qv.Yb[a2 * K + c]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes are done before its lanes read each other's
+            }
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const uint32_t e = e0 + 64u * t + lane;
+                T qi = part[t][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) qi += part[t][j];
+                if (any_more) qi += T(exw[64 * t + lane]);
+                const T ri = rv[t] - al[t] * qi;
+                T one[1] = {ri};
+                buf_store<T, 1>(rr, e < N ? e * S : kOutOfRange, one);
+                accv[t] += (e < NV || e >= N) ? 0.0 : double(ri) * double(ri) * double(dv[t]);
+            }
+            if (any_more) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile's zeros
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            double tsum = 0.0;
+#pragma unroll
+            for (int t = 0; t < K; ++t) tsum += (colof[t] == uint32_t(c)) ? accv[t] : 0.0;
+            acc[c] = tsum;
+        }
+        __syncthreads();
+        const double mine = block_sum_column<K>(acc, smem);
+        if (threadIdx.x < K) part_rz_next[blockIdx.x * K + threadIdx.x] = mine;
         return;
     }
     const int64_t i0 = fold.nb_flat > 0 ? ch.nv : 0;
@@ -1508,6 +1604,8 @@ __global__ void __launch_bounds__(256) k_cheb_pair(int64_t nv, const int32_t *__
 int g_slab_ahead = 1;      // remo_debug_tune key 27: 0 = the update launch walks the slab slots of a shared row one by one
 int g_slab_masked = 1;   // remo_debug_tune key 29: 0 = every row fetches four slab slots and weights the ones it does not have by zero (the form before)
 int g_flat_direction = 1;   // remo_debug_tune key 30: 1 (default) = the direction launch walks its vectors as flat arrays, 16 bytes per lane; 0 = a k-wide row per lane
+int g_tile_update = 1;      // remo_debug_tune key 31: 1 (default, fp64 storage) = the update launch takes 64 rows per wave, a value per lane and pass (k_pcg_update, tile form)
+void set_tile_update(int v) { g_tile_update = v ? 1 : 0; }
 void set_flat_direction(int v) { g_flat_direction = v ? 1 : 0; }
 void set_slab_masked(int v) { g_slab_masked = v ? 1 : 0; }
 void set_slab_ahead(int v) { g_slab_ahead = v ? 1 : 0; }
@@ -1685,6 +1783,10 @@ template <class T> void launch_pcg_update(const CsrViewT<T> &A, int k, int step,
     if (qv.bptr && g_slab_masked) {
         const uint64_t bytes = uint64_t(A.patch->t.nslot_cap) * uint64_t(k) * sizeof(T);
         qv.slab_bytes = bytes < 0xFFFFF000ull ? bytes : 0;
+        qv.row4 = A.patch->t.row4;
+        qv.tile = (g_tile_update && sizeof(T) == 8 && qv.slab_bytes && qv.row4 && qv.skip_x &&     // (fp32 storage: 256 bytes per wave and access - the row form is ahead there, 74.7 against 76.3 ms)
+                   uint64_t(n) * uint64_t(k) * sizeof(T) < 0xFFFFF000ull &&
+                   uint64_t(n) * 16 < 0xFFFFF000ull) ? 1 : 0;
     }
     const bool bins = b.pq_bins && b.defer_q && A.patch && !folded;
     const double *pq_rows = bins ? b.part_pq + (step & 1) * (kPqBins * 8) : b.part_pq;

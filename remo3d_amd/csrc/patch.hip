@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_patch_zero_rows(int64_t nslots, uint16_
 __global__ void __launch_bounds__(256) k_patch_slots(int E, int rows_cap, const int32_t *__restrict__ pcount, const int32_t *__restrict__ pboff,
                                                      const int32_t *__restrict__ prow, int32_t *__restrict__ pout, const int32_t *__restrict__ adjptr,
                                                      const uint32_t *__restrict__ adj, const int32_t *__restrict__ bptr, int32_t *__restrict__ bslot,
-                                                     int row_major) {
+                                                     int row_major, int32_t *__restrict__ row4) {
     __shared__ int32_t cnts[256];
     const int tid = threadIdx.x;
     const int64_t p = blockIdx.x;
@@ -180,6 +180,13 @@ __global__ void __launch_bounds__(256) k_patch_slots(int E, int rows_cap, const 
         const int32_t at = row_major ? bptr[row] + rank : slot;
         pout[p * rows_cap + m] = at;
         bslot[bptr[row] + rank] = at;
+        // row4[row] = the row's first four slots side by side (-1: none; preset), so that the update launch finds them with ONE load
+        // instead of two dependent ones; a row of five or more patches (vertex rows) keeps three there and -2 = "the rest is in bslot"
+        if (row4) {
+            const int32_t cnt = bptr[row + 1] - bptr[row];
+            if (rank < 3 || (rank == 3 && cnt <= 4)) row4[int64_t(row) * 4 + rank] = at;
+            else if (rank == 3) row4[int64_t(row) * 4 + 3] = -2;
+        }
         ++slot;
     }
 }
@@ -1238,7 +1245,7 @@ size_t patch_arena_bytes(int64_t nt, int64_t n_max, int kmax) {
     const int E = patch_elements_per_group(kmax);
     const int64_t npatch = (nt + E - 1) / E;
     const int64_t cap = int64_t(E) * 20;
-    return size_t(nt) * 40 + size_t(npatch) * (16 + 12 * size_t(cap)) + size_t(n_max + 2) * 8 + size_t(npatch) * 8 * 8 + (1 << 20);
+    return size_t(nt) * 40 + size_t(npatch) * (16 + 12 * size_t(cap)) + size_t(n_max + 2) * 8 + size_t(n_max + 1) * 16 + size_t(npatch) * 8 * 8 + (1 << 20);
 }
 
 // Everything is enqueued on s; flag_and_max (device, two ints) must be read by the caller after its next synchronisation:
@@ -1264,6 +1271,8 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     out.all_slab = (g_patch_all_slab && !g_patch_slab_rows) ? 1 : 0;
     out.nslot_cap = out.npatch * int64_t(rows_cap) < nt * 20 ? out.npatch * int64_t(rows_cap) : nt * 20;
     int32_t *bslot = ar.lo<int32_t>(size_t(out.nslot_cap) + 2);
+    int32_t *row4 = out.all_slab ? ar.lo<int32_t>(size_t(n) * 4 + 4) : nullptr;
+    if (row4) (void)hipMemsetAsync(row4, 0xFF, sizeof(int32_t) * size_t(n) * 4, s);
     const size_t mark = ar.hi_mark();
     int32_t *bcnt = ar.hi<int32_t>(size_t(n) + 2);
     int32_t *pboff = ar.lo<int32_t>(size_t(out.npatch) + 2);
@@ -1282,10 +1291,10 @@ void build_patch_tables(Arena &ar, hipStream_t s, const DeviceSymbolic &sy, cons
     (void)rocprim::exclusive_scan(tmp, tb2, pbcnt, pboff, int32_t(0), size_t(out.npatch + 1), rocprim::plus<int32_t>(), s);
     hipLaunchKernelGGL(k_patch_zero_rows, dim3(1024), dim3(256), 0, s, nt * 20, lidx, (const int32_t *)(flag_and_max + 1));
     hipLaunchKernelGGL(k_patch_slots, dim3(int(out.npatch)), dim3(256), 0, s, E, rows_cap, (const int32_t *)pcount, (const int32_t *)pboff, (const int32_t *)prow, pout,
-                       sy.adjptr, sy.adj, (const int32_t *)bptr, bslot, g_patch_slab_rows);
+                       sy.adjptr, sy.adj, (const int32_t *)bptr, bslot, g_patch_slab_rows, row4);
     (void)hipMemcpyAsync(flag_and_max + 2, out.all_slab ? pboff + out.npatch : bptr + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // slab slots in use (all_slab: blocks padded to 16 rows)
     ar.hi_release(mark);     // the stream orders later users of this scratch behind these launches
-    out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.pboff = pboff; out.bptr = bptr; out.bslot = bslot;
+    out.lidx = lidx; out.pcount = pcount; out.prow = prow; out.pout = pout; out.pboff = pboff; out.row4 = row4; out.bptr = bptr; out.bslot = bslot;
 }
 
 template <class T, int K> static void patch_dispatch(const CsrViewT<T> &A, const T *x, T *y, double *part, const double *scal, int step, int nb, hipStream_t s, bool defer) {

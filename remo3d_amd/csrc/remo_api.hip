@@ -1499,6 +1499,7 @@ int remo_debug_tune(int32_t key, int32_t value) {
         case 16: g_amg = value; return 0;               // multigrid cycle on the vertex block
         case 17: g_amg32 = value; return 0;             // ... in fp32 storage
         case 18: set_element_order(value); return 0;    // elements in the caller's order
+        case 31: set_tile_update(value); return 0;      // update launch: 64 rows per wave, a value per lane and pass / a k-wide row per lane
         case 30: set_flat_direction(value); return 0;   // direction launch: flat arrays, 16 bytes per lane / a k-wide row per lane
         case 29: set_slab_masked(value); return 0;      // slab slots a row does not have: not fetched / fetched and weighted by zero
         case 25: g_x_in_direction = value; return 0;    // x += alpha p in the direction / in the update launch

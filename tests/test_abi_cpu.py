@@ -94,7 +94,7 @@ def test_probe_keys_are_not_in_the_product_library():
     experiments and ablations - some give wrong results on purpose - exist only in the -DREMO_PROBES build and return -1 here."""
     from remo3d_amd import _lib
     L = _lib.load()
-    for key, default in ((3, -1), (6, 1), (9, 1), (13, 1), (15, 1), (16, 0), (17, 1), (18, 1), (22, 1), (24, 1), (25, 1), (29, 1), (30, 1)):
+    for key, default in ((3, -1), (6, 1), (9, 1), (13, 1), (15, 1), (16, 0), (17, 1), (18, 1), (22, 1), (24, 1), (25, 1), (29, 1), (30, 1), (31, 1)):
         assert L.remo_debug_tune(key, default) == 0, key
     for key in (0, 1, 2, 4, 5, 7, 8, 19, 20, 21, 23, 26, 27, 28, 32, 33, 34, 35, 36, 37, 38, 99):
         assert L.remo_debug_tune(key, 0) == -1, key

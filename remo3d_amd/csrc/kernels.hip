@@ -835,11 +835,21 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t n, int step, double 
         }
         double *exw = ex_lds + wave * (64 * K);
         const uint32_t nwaves = uint32_t(gridDim.x) * 4u;
+        // (the slots of the NEXT tile are requested before this tile's values: one memory round trip per tile on a wave's critical path, not two)
+        int32_t w4n[4];
+        {
+            const uint32_t row0 = (uint32_t(blockIdx.x) * 4u + wave) * 64u + lane;
+            buf_load<int32_t, 4>(r4, row0 < uint32_t(n) ? row0 * 16u : kOutOfRange, w4n);
+        }
         for (uint32_t R0 = (uint32_t(blockIdx.x) * 4u + wave) * 64u; R0 < uint32_t(n); R0 += nwaves * 64u) {
             const uint32_t myrow = R0 + lane;
             int32_t w4[4];
-            buf_load<int32_t, 4>(r4, myrow < uint32_t(n) ? myrow * 16u : kOutOfRange, w4);
-            if (myrow >= uint32_t(n)) { w4[0] = w4[1] = w4[2] = w4[3] = -1; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[j] = myrow < uint32_t(n) ? w4n[j] : -1;
+            {
+                const uint32_t nrow = myrow + nwaves * 64u;
+                buf_load<int32_t, 4>(r4, nrow < uint32_t(n) ? nrow * 16u : kOutOfRange, w4n);
+            }
             const uint32_t e0 = R0 * uint32_t(K);
             T rv[K], dv[K], part[K][4];
 #pragma unroll

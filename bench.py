@@ -426,9 +426,26 @@ class Runner:
         t_busy = time.time()
         nctx = len(self.ctxs)
         if h2d_inclusive:     # the host-buffer entry: every batch is copied to the device inside the timed span (remo_solve_batch)
+            # as Model.simulate_logs drives its contexts: whichever context is free takes the rank's next batch (REMO_BENCH_CTX_DRAW=static:
+            # context j takes batches j, j + nctx, ... - the rule before, kept for the A/B)
+            import itertools, threading
+            draw, draw_lock = itertools.count(), threading.Lock()
+            static_draw = os.environ.get("REMO_BENCH_CTX_DRAW") == "static"
+
+            def my_batches(j):
+                if static_draw:
+                    yield from range(j, len(self.work), nctx)
+                    return
+                while True:
+                    with draw_lock:
+                        i = next(draw)
+                    if i >= len(self.work):
+                        return
+                    yield i
+
             def drive_h(j):
                 res = []
-                for i in range(j, len(self.work), nctx):
+                for i in my_batches(j):
                     w = self.work[i]
                     outs, st, rc = self.ctxs[j].solve_batch(w["mesh"], w["sigma"], w["sources"], w["evals"], self._opts(i), raise_on_error=False)
                     res.append((i, rc, st, outs))
@@ -599,7 +616,7 @@ def main():
     ap.add_argument("--op", default="auto", choices=["auto", "csr", "patch"],
                     help="how the CG applies A: csr = SpMM on the assembled matrix; patch = matrix-free through the factorised reference tensors, "
                          "patch by patch with LDS-staged vectors; auto (the library's default) = patch in 3D")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=5,
                     help="contexts (HIP streams + arenas) per GPU, each driven by its own host thread over its share of the batches; "
                          "3 = the headline configuration and Model's default, model.DEFAULT_CONTEXTS (the launch-latency-bound part of one batch's PCG step is filled by the others' kernels)")
     ap.add_argument("--resident", action="store_true",

@@ -35,8 +35,12 @@ DEFAULT_SCALE = {2: 0.35, 3: 1.0}
 
 # Contexts (HIP stream + arena + host thread) per GPU when the caller does not say (gpu_workers = 0).  bench.py, size L, same box,
 # points/s on SURVEY 8d's span: 1 context 91-101, 2: 109.7-110.3 / 115.3-115.9, 3: 113.3-113.4 / 117.2, 4: 110.1
-# (profiles/r04_i_bench_streams*.json, r04_c_bench_streams*.json).
-DEFAULT_CONTEXTS = 3
+# (profiles/r04_i_bench_streams*.json, r04_c_bench_streams*.json) - all with the HIP runtime's default of four hardware queues,
+# where the fourth context shares a queue with another stream of the process.  With eight (remo3d_amd/__init__.py), end of round 4,
+# alternating runs on one box: 3 contexts 159.9-160.0, 4: 157.9-160.6, 5: 168.1-168.3, 6: 165.7-166.5, 8: 163.8-165.2
+# (profiles/r04_bl_hw_queues_and_contexts.json).
+DEFAULT_CONTEXTS = 5
+MAX_CONTEXTS = 8
 
 
 def lattice_mesh_key(dim, domain_radius, batch, scale, seed=0) -> tuple:
@@ -269,8 +273,8 @@ class Model:
         """The reference spawns MPI workers here (remo3d.py:552-599); this build opens GPU contexts in the
         calling process (device = LOCAL_RANK under torchrun): `gpu_workers` of them (0, the default, = DEFAULT_CONTEXTS), each
         with its own HIP stream and arena and driven by its own host thread in simulate_logs, so batches
-        overlap on the GPU the way the reference's GPU workers overlap (three fill the launch-latency gaps of
-        one: +15-25 % in 3D, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
+        overlap on the GPU the way the reference's GPU workers overlap (they fill the launch-latency gaps of
+        one another: +40 % in 3D at five, more in 2D).  Parallelism ACROSS GPUs comes from the launcher (one rank per GPU);
         cpu_workers is validated like the reference and sizes the pool of mesh-generating processes (there is no CPU
         solver).  Under torchrun this is also where the rank joins the process group (sweep.init_from_env)."""
         if type(cpu_workers) != int or type(gpu_workers) != int:
@@ -288,10 +292,10 @@ class Model:
         device = int(os.environ.get("REMO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         make = context_factory or solver.Context     # context_factory(device): a stand-in solver for the CPU tests of the sweep
         self.ctx = make(device)
-        # contexts on this GPU: gpu_workers of them (at most 4); the reference's default gpu_workers = 0 means "no GPU worker"
+        # contexts on this GPU: gpu_workers of them (at most MAX_CONTEXTS); the reference's default gpu_workers = 0 means "no GPU worker"
         # there and "the build's default" here: DEFAULT_CONTEXTS - the launch-latency-bound quarter of one batch's PCG step (the
         # chain of small launches on the vertex block) is filled by the other batches' kernels
-        n_ctx = DEFAULT_CONTEXTS if gpu_workers == 0 else min(gpu_workers, 4)
+        n_ctx = DEFAULT_CONTEXTS if gpu_workers == 0 else min(gpu_workers, MAX_CONTEXTS)
         self.extra_ctx = [make(device) for _ in range(n_ctx - 1)]
 
     def shutdown_workers(self):

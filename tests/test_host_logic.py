@@ -223,3 +223,16 @@ def test_vertex_solver_rule_of_the_model():
         assert opts.coarse == 3 and opts.coarse_degree == o["coarse_degree"]
     with pytest.raises(ValueError):
         solver.make_opts(coarse="ilu")
+
+
+def test_package_import_asks_for_eight_hardware_queues_unless_the_caller_chose():
+    """remo3d_amd/__init__.py: GPU_MAX_HW_QUEUES (read by the HIP runtime at its first call) defaults to 8 - one queue per context
+    stream of a Model with DEFAULT_CONTEXTS - and a caller's own value is left alone."""
+    import subprocess, sys
+    code = "import os, remo3d_amd, remo3d_amd.model as m; print(os.environ['GPU_MAX_HW_QUEUES'], m.DEFAULT_CONTEXTS, m.MAX_CONTEXTS)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == 8 and int(out[1]) <= int(out[0]) and int(out[1]) <= int(out[2])
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == 4

@@ -12,8 +12,8 @@ the image), size L = 1.2 x that field; their sizes (T, n, nnz) are printed in th
 One "step" = one pass of the hot path over every batch of the sweep, the way the product runs it
 (`Model` / worker.py:74-142): per batch host arrays -> device (remo_solve_batch), dof numbering, the
 assembly the operator needs, multi-RHS two-level PCG, axis evaluation, potentials -> host, apparent
-resistivity — THREE contexts per GPU (streams + arenas, one host thread each) take the batches in turn, as
-`Model` does by default — then ONE all-reduce of the log slab across ranks (RCCL).  The timed span is
+resistivity — FIVE contexts per GPU (streams + arenas, one host thread each; eight hardware queues: remo3d_amd/__init__.py) draw the
+batches one after the other, as `Model` does by default — then ONE all-reduce of the log slab across ranks (RCCL).  The timed span is
 SURVEY.md 8d's: H2D of the mesh arrays ... D2H of the potentials; mesh generation is excluded (8d) and
 reported beside it.  `value` comes from that span.  Per-kernel figures (`roofline`, `breakdown`) come
 from a second, single-context leg with the batches resident (kernels that share the chip cannot be

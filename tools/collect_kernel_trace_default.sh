@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the DEFAULT bench command's headline leg (three contexts, SURVEY 8d's span, the vertex-block solver Model picks),
-# condensed by tools/ktrace_stats.py.  Kernels of three contexts share the chip here: durations are those of the product's operating mode,
+# rocprofv3 kernel trace of the DEFAULT bench command's headline leg (five contexts, SURVEY 8d's span, the vertex-block solver Model picks),
+# condensed by tools/ktrace_stats.py.  Kernels of five contexts share the chip here: durations are those of the product's operating mode,
 # not of a kernel alone (for that: tools/collect_kernel_trace.sh, one context).  An un-profiled run first fills the on-disk mesh cache.
 # usage (GPU box, repo root): bash tools/collect_kernel_trace_default.sh OUT_PREFIX [bench args...]
 set -e

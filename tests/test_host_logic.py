@@ -236,3 +236,25 @@ def test_package_import_asks_for_eight_hardware_queues_unless_the_caller_chose()
     assert int(out[0]) == 8 and int(out[1]) <= int(out[0]) and int(out[1]) <= int(out[2])
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, GPU_MAX_HW_QUEUES="4"), capture_output=True, text=True, check=True).stdout.split()
     assert int(out[0]) == 4
+
+
+def test_initialize_workers_opens_the_default_number_of_contexts_and_caps_the_callers():
+    """Model.initialize_workers (remo3d.py:552-599's keywords): gpu_workers = 0 opens model.DEFAULT_CONTEXTS contexts on the rank's GPU,
+    gpu_workers = k opens k of them, at most model.MAX_CONTEXTS (one hardware queue each: remo3d_amd/__init__.py)."""
+    from remo3d_amd import model
+
+    class Stub:
+        opened = 0
+
+        def __init__(self, device):
+            Stub.opened += 1
+
+        def close(self):
+            pass
+
+    for asked, expect in ((0, model.DEFAULT_CONTEXTS), (1, 1), (3, 3), (50, model.MAX_CONTEXTS)):
+        Stub.opened = 0
+        m = Model(["A0.4M6.0N"])
+        m.initialize_workers(cpu_workers=1, gpu_workers=asked, context_factory=Stub)
+        assert Stub.opened == expect and 1 + len(m.extra_ctx) == expect
+        m.shutdown_workers()
